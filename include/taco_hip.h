@@ -1,0 +1,143 @@
+/* taco_hip.h -- C-ABI of the MI355X-native (gfx950) Tacotron multispeaker training-step kernels.
+ *
+ * The reference (Jim-Song/tacotron_multispeaker) has NO native/FFI layer: its training step is a TF-1.x
+ * graph built by models/tacotron.py:18-195 and executed by sess.run at train.py:142-146.  This header is
+ * therefore the build's own boundary: each entry point below names the reference graph
+ * op(s) it replaces.  The Python mirror of the reference construction API (hparams.py, models/, datasets/,
+ * train.py at the repo root) drives these through ctypes (tacotron_multispeaker_amd/_lib.py parses THIS file).
+ *
+ * Conventions
+ *   - every function returns 0 on success, -22 (EINVAL) on bad arguments, or the hipError_t of a failed launch;
+ *     nothing throws, allocates, frees or synchronises: all work is enqueued asynchronously on `stream`
+ *     (HIP-graph capturable); the caller owns every buffer.
+ *   - tensors are row-major fp32, channel-last exactly like the reference tensors ([N,T,C] == [N*T, C] with a
+ *     leading dimension `ld*` in floats); ids / lengths / global_step are int32; reduction scratch is double.
+ *   - leading dimensions and channel counts must be multiples of 4 and base pointers 16-byte aligned
+ *     (all kernels move 16 B per lane).
+ */
+#ifndef TACO_HIP_H
+#define TACO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+/* ---- dense / conv1d('same') / CBHG conv bank as fp32-MFMA implicit GEMM ------------------------------------
+ * replaces tf.layers.dense (models/modules.py:10,79-89; models/tacotron.py:101) and tf.layers.conv1d
+ * (models/modules.py:95-100) incl. the K-wide conv bank (models/modules.py:39-42).
+ * X [M=N*T, Cin]; W TF layout [kw, Cin, Cout] (ldw = row stride of the [Cin, Cout] slices); Y [M, Cout].
+ * bank_K > 0: fused bank of widths 1..bank_K, 128 channels each, W packed [sum k][Cin][128], Y [M, bank_K*128].
+ * act: 0 none, 1 relu, 2 sigmoid, 3 tanh.  Dense layer: kw = 1, T = M. */
+int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin, int Cout,
+                       int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate, hipStream_t stream);
+/* dX (+)= conv_transpose(dY, W)   (gradient of the above wrt X) */
+int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* dX, int M, int T, int Cin, int Cout, int kw,
+                            int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream);
+/* dW += X^T (shifted per tap) . dY   (atomic accumulation into a zeroed / running gradient buffer) */
+int taco_conv_gemm_bwd_weight(const float* X, const float* dY, float* dW, int M, int T, int Cin, int Cout, int kw,
+                              int bank_K, int ldx, int lddy, int ldw, hipStream_t stream);
+/* dW[K,N] += sum_m X[m+shift, :]^T dY[m, :], rows leaving their length-T sequence contribute 0 (recurrent weights) */
+int taco_gemm_tn_shift(const float* X, const float* dY, float* dW, int M, int T, int K, int N, int ldx, int lddy,
+                       int ldw, int shift, hipStream_t stream);
+
+/* ---- embeddings: tf.nn.embedding_lookup + speaker lookup/tile/concat (models/tacotron.py:42-55) -------------- */
+int taco_embed_gather_fwd(const int* ids, const int* identities, const float* table, const float* spk_table, float* out,
+                          int N, int Ti, int Et, int Es, int vocab, int id_num, hipStream_t stream);
+/* scatter-add of dE [N*Ti, Et+Es] into the tables; sparse_sumsq[0] += sum of squares of the un-deduplicated
+ * IndexedSlices rows (tf.global_norm quirk); may be NULL */
+int taco_embed_scatter_bwd(const int* ids, const int* identities, const float* dE, float* dTable, float* dSpk,
+                           double* sparse_sumsq, int N, int Ti, int Et, int Es, int vocab, int id_num, hipStream_t stream);
+
+/* ---- batch norm (tf.layers.batch_normalization, models/modules.py:101), maxpool (modules.py:45-49), residual -- */
+int taco_col_sum(const float* x, int ldx, float* out, int M, int C, hipStream_t stream);   /* out[c] += sum_m x[m,c] */
+int taco_bn_stats_fwd(const float* x, int ldx, const float* gamma, const float* beta, double* dstat_zeroed, float* mean,
+                      float* var, float* rstd, float* scale, float* shift, int M, int C, float eps, hipStream_t stream);
+int taco_bn_infer_params(const float* moving_mean, const float* moving_var, const float* gamma, const float* beta,
+                         float* scale, float* shift, int C, float eps, hipStream_t stream);
+/* y = [max over (t, t+1)] (x*scale+shift) [+ res] */
+int taco_bn_apply_fwd(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldr, float* y,
+                      int ldy, int M, int C, int T, int pool, hipStream_t stream);
+/* dy = gradient wrt the BN output (pool=1: wrt the pooled output); dx = gradient wrt the conv pre-activation
+ * (relu=1 applies the conv's ReLU mask); dgamma/dbeta are ADDED */
+int taco_bn_bwd(const float* x, int ldx, const float* dy, int lddy, const float* mean, const float* rstd,
+                const float* scale, const float* shift, const float* gamma, double* dstat_zeroed, float* dgamma,
+                float* dbeta, float* dx, int lddx, int M, int C, int T, int pool, int relu, hipStream_t stream);
+
+/* ---- highway gating (models/modules.py:77-90); Z [M,256] = x.[W_H|W_T]+b in, [relu(H), sigmoid(T)] out -------- */
+int taco_highway_gate_fwd(float* Z, const float* x, float* y, int M, hipStream_t stream);
+int taco_highway_gate_bwd(const float* HT, const float* x, const float* dy, float* dZ, float* dx, int M, hipStream_t stream);
+int taco_relu_bwd(const float* y, const float* dy, float* dpre, long n, hipStream_t stream);
+int taco_add(const float* a, const float* b, float* y, long n, int accumulate, hipStream_t stream);
+
+/* ---- L1 losses + sign gradients (models/tacotron.py:127-137) ---------------------------------------------------- */
+int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2, long rows,
+                 int C, int npri, float w_all, float w_pri, hipStream_t stream);
+
+/* ---- persistent (bi)GRU(128) sequence kernels: tf.nn.bidirectional_dynamic_rnn (models/modules.py:68-74) -------
+ * xp [N,T,ldxp]: hoisted x.W_x + b per direction d at columns [d*384, d*384+384) ordered r|u|c;
+ * wg [128,256], wc [128,128]: recurrent halves of the GRUCell gates/candidate kernels;
+ * out [N,T,ldo] direction d at columns [d*128, ..); ruc [ndir,N,T,384] saved gates for BPTT. */
+int taco_gru128_seq_fwd(const float* xp, int ldxp, const float* wg_fw, const float* wc_fw, const float* wg_bw,
+                        const float* wc_bw, const int* lengths, float* out, int ldo, float* ruc, int N, int T, int ndir,
+                        hipStream_t stream);
+int taco_gru128_seq_bwd(const float* dout, int lddo, const float* wg_fw, const float* wc_fw, const float* wg_bw,
+                        const float* wc_bw, const int* lengths, const float* out, int ldo, const float* ruc, float* dxp,
+                        int ldxp, float* hp, float* rh, int N, int T, int ndir, hipStream_t stream);
+
+/* ---- attention decoder (models/tacotron.py:66-97, rnn_wrappers.py, helpers.py:41-82) ---------------------------- */
+int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int num_mels, hipStream_t stream);
+/* attention recurrence; ptrs = device pointer table indexed by enum TacoAttnPtr, dims = {N, S, Ti} (host arrays) */
+int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t stream);
+int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stream);
+/* residual decoder GRU(256) with hoisted input projection xp [N,S,768]; d = res + h when d != NULL */
+int taco_gru256_seq_fwd(const float* xp, const float* whg, const float* whc, const float* res, float* r, float* u, float* c,
+                        float* rh, float* h, float* d, const float* zeros, int N, int S, hipStream_t stream);
+int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, const float* r, const float* u, const float* c,
+                        const float* h, float* dxp, float* dhT, float* dhpart, const float* zeros, int N, int S,
+                        hipStream_t stream);
+
+/* ---- optimizer: tf.clip_by_global_norm + tf.train.AdamOptimizer + Noam lr + BN UPDATE_OPS (tacotron.py:174-202) -- */
+int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream);
+int taco_adam_step(float* params, const float* grads, float* m, float* v, long n, const double* gnorm2,
+                   const int* global_step, float init_lr, int decay, float beta1, float beta2, float eps, float clip,
+                   float* info3, hipStream_t stream);
+int taco_bn_ema(float* moving, const float* batch, int n, float momentum, hipStream_t stream);
+int taco_step_inc(int* global_step, hipStream_t stream);
+int taco_scale(float* x, long n, float s, hipStream_t stream);
+
+/* pointer-table slots of taco_attn_rnn_fwd / taco_attn_rnn_bwd (all fp32 device pointers) */
+enum TacoAttnPtr {
+    TACO_AP_W1C = 0,   /* decoder_prenet dense_1 kernel rows 80:336 (context part)  [256,256] */
+    TACO_AP_F1,        /* hoisted frame part of dense_1 (+bias)                     [N,S,256] */
+    TACO_AP_W2, TACO_AP_B2,   /* decoder_prenet dense_2                             [256,128],[128] */
+    TACO_AP_WX,        /* attention GRU input weights, gates|candidate              [128,768] */
+    TACO_AP_WHG,       /* attention GRU recurrent gate weights                      [256,512] */
+    TACO_AP_WHC,       /* attention GRU recurrent candidate weights                 [256,256] */
+    TACO_AP_BG,        /* attention GRU biases gates|candidate                      [768] */
+    TACO_AP_WQ, TACO_AP_V,    /* BahdanauAttention query_layer kernel, attention_v   [256,256],[256] */
+    TACO_AP_KEYS,      /* memory_layer(encoder_outputs)                             [N,Ti,256] */
+    TACO_AP_MEM,       /* encoder_outputs (attention values)                        [N,Ti,256] */
+    TACO_AP_ZEROS,     /* >= N*256 zeros (initial states)                            */
+    TACO_AP_P1, TACO_AP_P2,                      /* saved prenet activations  [N,S,256],[N,S,128] */
+    TACO_AP_R, TACO_AP_U, TACO_AP_C, TACO_AP_RH, /* saved GRU gates           [N,S,256] each */
+    TACO_AP_HC,        /* [h_s | ctx_s] (input of the concat projection)            [N,S,512] */
+    TACO_AP_Q,         /* saved queries                                             [N,S,256] */
+    TACO_AP_ALIGN,     /* alignments a_s                                            [N,S,Ti] */
+    /* backward only */
+    TACO_AP_DHC,       /* in:  gradient wrt [h_s | ctx_s] from the concat projection [N,S,512] */
+    TACO_AP_DXP,       /* out: attention GRU pre-activation gradients               [N,S,768] */
+    TACO_AP_DP2, TACO_AP_DP1, /* out: prenet pre-activation gradients         [N,S,128],[N,S,256] */
+    TACO_AP_DQ,        /* out (pre-zeroed): query gradients                         [N,S,256] */
+    TACO_AP_DKEYS, TACO_AP_DMEM, /* out (pre-zeroed accumulators)                   [N,Ti,256] each */
+    TACO_AP_DVPART,    /* out (pre-zeroed): attention_v partial gradients  [N,ceil(Ti/16),256] */
+    TACO_AP_DA,        /* scratch [N,Ti] */
+    TACO_AP_DHT, TACO_AP_DHPART, TACO_AP_DHCARRY, TACO_AP_DCTX, TACO_AP_DCTXCARRY, /* scratch [N,256] each */
+    TACO_AP_COUNT
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TACO_HIP_H */

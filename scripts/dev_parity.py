@@ -1,0 +1,64 @@
+"""Dev script: end-to-end parity of the HIP engine vs the float64 torch oracle (run on the GPU box)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import tacotron_np as onp, tacotron_torch as ot
+from tacotron_multispeaker_amd.engine import Engine
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+def run(N, Ti, To, r, idn, seed=3, wscale=1.0):
+    print('=== config', N, Ti, To, r, idn, flush=True)
+    P = onp.init_params(seed=seed, r=r, id_num=idn)
+    if wscale != 1.0:
+        rng = np.random.RandomState(99)
+        for k in P:
+            if k.endswith('/bias') or k.endswith('/beta'): P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+            if k.endswith('/gamma'): P[k] = P[k] * (1 + 0.2 * rng.standard_normal(P[k].shape))
+    b = onp.synth_batch(N, Ti, To, r, seed=11, id_num=idn)
+    ts = ot.TrainState(P, torch.float64, id_num=idn, r=r)
+    t = time.time(); last = ts.forward_backward(b); print('oracle fwd+bwd %.1fs' % (time.time() - t), flush=True)
+    eng = Engine(id_num=idn, r=r, named_params=P)
+    dev = eng.dev
+    inputs = torch.tensor(b['inputs'], device=dev); lens = torch.tensor(b['input_lengths'], device=dev)
+    mel = torch.tensor(b['mel_targets'], device=dev); lin = torch.tensor(b['linear_targets'], device=dev)
+    ids = torch.tensor(b['identities'], device=dev) if idn > 1 else None
+    eng.forward(inputs, lens, mel, ids)
+    eng.loss(lin)
+    torch.cuda.synchronize()
+    o = last['out']
+    print('enc   rel', rel(eng.encoder_outputs.cpu().numpy(), o['encoder_outputs'].detach().numpy()))
+    print('mel   rel', rel(eng.mel_outputs.cpu().numpy(), o['mel_outputs'].detach().numpy()))
+    print('lin   rel', rel(eng.linear_outputs.cpu().numpy(), o['linear_outputs'].detach().numpy()))
+    print('align rel', rel(eng.alignments.cpu().numpy(), o['alignments'].detach().numpy()))
+    print('loss', eng.loss_values(), last['loss'], last['mel_loss'], last['linear_loss'])
+    eng.backward()
+    torch.cuda.synchronize()
+    g = eng.export_named('grads')
+    worst = []
+    for k, v in last['grads'].items():
+        e = rel(g[k], v.numpy())
+        worst.append((e, k, float(np.abs(v.numpy()).max())))
+    worst.sort(reverse=True)
+    for e, k, m in worst[:12]: print('  grad %-55s rel %.2e  max %.2e' % (k, e, m))
+    print('  grad median rel %.2e' % np.median([w[0] for w in worst]))
+    info = ts.apply(last)
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    print('gnorm', eng.info[:3].cpu().numpy(), info)
+    pn = eng.export_named('params')
+    worst = []
+    for k, v in ts.P.items():
+        d = np.abs(pn[k] - v.detach().numpy()).max()
+        worst.append((float(d), k))
+    worst.sort(reverse=True)
+    for e, k in worst[:6]: print('  param %-55s absdiff %.2e' % (k, e))
+
+if __name__ == '__main__':
+    torch.set_num_threads(16)
+    run(2, 12, 20, 5, 0)
+    run(3, 21, 24, 2, 4, wscale=2.0)
+    if len(sys.argv) > 1:
+        run(4, 48, 120, 5, 0)

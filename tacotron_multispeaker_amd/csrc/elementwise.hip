@@ -1,0 +1,463 @@
+// HBM-bound streaming kernels of the Tacotron training step (gfx950): embedding gather/scatter,
+// batch-norm statistics / apply (+ fused maxpool, residual) forward and backward, highway gating,
+// L1 losses with in-place sign gradients, column sums (bias gradients).
+// All tensors are channel-last row-major fp32; channel counts are multiples of 4 so every thread moves
+// 16 B per access (global_load_dwordx4), rows are covered by consecutive lanes -> fully coalesced.
+#include "common.hpp"
+
+// =====================================================================================================
+// Embedding  (reference models/tacotron.py:42-55: embedding_lookup + speaker lookup/tile/concat)
+// =====================================================================================================
+__global__ void embed_gather_k(const int* __restrict__ ids, const int* __restrict__ identities,
+                               const float* __restrict__ table, const float* __restrict__ spk, float* __restrict__ out,
+                               int N, int Ti, int Et, int Es, int vocab, int id_num) {
+    const int E = Et + Es, e4 = E / 4;
+    const long total = (long)N * Ti * e4;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % e4) * 4;
+        const long row = idx / e4;
+        float4 v;
+        if (c < Et) {
+            int id = ids[row];
+            id = min(max(id, 0), vocab - 1);
+            v = *reinterpret_cast<const float4*>(table + (long)id * Et + c);
+        } else {
+            int sid = identities[row / Ti];
+            sid = min(max(sid, 0), id_num - 1);
+            v = *reinterpret_cast<const float4*>(spk + (long)sid * Es + (c - Et));
+        }
+        *reinterpret_cast<float4*>(out + row * E + c) = v;
+    }
+}
+
+// dTable[ids[row]] += dE[row, :Et]; also accumulates sum of squares of the un-deduplicated rows
+// (tf.global_norm over IndexedSlices.values) into sumsq[0].
+__global__ void embed_scatter_text_k(const int* __restrict__ ids, const float* __restrict__ dE, float* __restrict__ dTable,
+                                     double* __restrict__ sumsq, int rows, int Et, int E, int vocab) {
+    const int e4 = Et / 4;
+    const long total = (long)rows * e4;
+    float ss = 0.0f;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % e4) * 4;
+        const long row = idx / e4;
+        const float4 g = *reinterpret_cast<const float4*>(dE + row * E + c);
+        int id = min(max(ids[row], 0), vocab - 1);
+        float* d = dTable + (long)id * Et + c;
+        atomicAdd(d + 0, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+        ss += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    }
+    double w = wave_sum_d((double)ss);
+    if ((threadIdx.x & 63) == 0 && sumsq) atomicAdd(sumsq, w);
+}
+
+// dSpk[identities[n]] += sum_t dE[n,t,Et:]; one block per n; sumsq[0] += |sum_t ...|^2
+__global__ void embed_scatter_spk_k(const int* __restrict__ identities, const float* __restrict__ dE,
+                                    float* __restrict__ dSpk, double* __restrict__ sumsq, int Ti, int Et, int Es, int id_num) {
+    const int n = blockIdx.x, E = Et + Es;
+    __shared__ float part[256];
+    const int c = threadIdx.x % Es, lane_t = threadIdx.x / Es, nt = blockDim.x / Es;
+    float s = 0.0f;
+    if (lane_t < nt)
+        for (int t = lane_t; t < Ti; t += nt) s += dE[((long)n * Ti + t) * E + Et + c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < Es) {
+        float tot = 0.0f;
+        for (int k = 0; k < nt; ++k) tot += part[k * Es + threadIdx.x];
+        int sid = min(max(identities[n], 0), id_num - 1);
+        atomicAdd(dSpk + (long)sid * Es + threadIdx.x, tot);
+        if (sumsq) atomicAdd(sumsq, (double)tot * (double)tot);
+    }
+}
+
+// =====================================================================================================
+// Column reductions over [M, C] (C % 4 == 0): thread = one float4 column group, 4 row lanes per block
+// =====================================================================================================
+// MODE 0: sum(x)                     -> out0           (bias gradients)          [float atomics]
+// MODE 1: sum(x), sum(x^2)           -> dstat[0:C], dstat[C:2C]   (BN statistics) [double atomics]
+// MODE 2: sum(db), sum(db*xhat)      -> dstat             (BN backward; db from dY or through maxpool)
+struct ColRed {
+    const float* x; int ldx;
+    const float* dy; int lddy;          // MODE 2: gradient wrt BN output (or wrt pooled output when pool)
+    const float* mean; const float* rstd; const float* scale; const float* shift;
+    float* out0; double* dstat;
+    int M, C, T, pool, rows_per_block;
+};
+
+__device__ __forceinline__ float4 f4fma(float4 a, float4 s, float4 b) {
+    return make_float4(fmaf(a.x, s.x, b.x), fmaf(a.y, s.y, b.y), fmaf(a.z, s.z, b.z), fmaf(a.w, s.w, b.w));
+}
+
+// gradient wrt the BN output at row m for 4 channels; with pool: routed through max(b[t], b[t+1])
+// (first max wins ties, like TF CPU MaxPoolGrad / torch max_pool1d)
+__device__ __forceinline__ float4 bn_out_grad(const ColRed& p, long m, int c, float4 xv, float4 sc, float4 sh) {
+    const float4 g = *reinterpret_cast<const float4*>(p.dy + m * p.lddy + c);
+    if (!p.pool) return g;
+    const int t = (int)(m % p.T);
+    const float4 b = f4fma(xv, sc, sh);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t == p.T - 1) r = g;
+    else {
+        const float4 bn = f4fma(*reinterpret_cast<const float4*>(p.x + (m + 1) * p.ldx + c), sc, sh);
+        r.x = b.x >= bn.x ? g.x : 0.f; r.y = b.y >= bn.y ? g.y : 0.f; r.z = b.z >= bn.z ? g.z : 0.f; r.w = b.w >= bn.w ? g.w : 0.f;
+    }
+    if (t > 0) {
+        const float4 bp = f4fma(*reinterpret_cast<const float4*>(p.x + (m - 1) * p.ldx + c), sc, sh);
+        const float4 gp = *reinterpret_cast<const float4*>(p.dy + (m - 1) * p.lddy + c);
+        r.x += b.x > bp.x ? gp.x : 0.f; r.y += b.y > bp.y ? gp.y : 0.f; r.z += b.z > bp.z ? gp.z : 0.f; r.w += b.w > bp.w ? gp.w : 0.f;
+    }
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_k(ColRed p) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + tx) * 4;
+    const bool active = c < p.C;
+    const long r0 = (long)blockIdx.y * p.rows_per_block;
+    const long r1 = min((long)p.M, r0 + p.rows_per_block);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    float4 sc = s0, sh = s0, mu = s0, rs = s0;
+    if (active && MODE == 2) {
+        mu = *reinterpret_cast<const float4*>(p.mean + c);
+        rs = *reinterpret_cast<const float4*>(p.rstd + c);
+        sc = *reinterpret_cast<const float4*>(p.scale + c);
+        sh = *reinterpret_cast<const float4*>(p.shift + c);
+    }
+    if (active)
+        for (long m = r0 + ty; m < r1; m += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + m * p.ldx + c);
+            if (MODE == 0) { s0.x += xv.x; s0.y += xv.y; s0.z += xv.z; s0.w += xv.w; }
+            else if (MODE == 1) {
+                s0.x += xv.x; s0.y += xv.y; s0.z += xv.z; s0.w += xv.w;
+                s1.x += xv.x * xv.x; s1.y += xv.y * xv.y; s1.z += xv.z * xv.z; s1.w += xv.w * xv.w;
+            } else {
+                const float4 g = bn_out_grad(p, m, c, xv, sc, sh);
+                s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+                s1.x += g.x * (xv.x - mu.x) * rs.x; s1.y += g.y * (xv.y - mu.y) * rs.y;
+                s1.z += g.z * (xv.z - mu.z) * rs.z; s1.w += g.w * (xv.w - mu.w) * rs.w;
+            }
+        }
+    __shared__ float4 red[2][4][64];
+    red[0][ty][tx] = s0; red[1][ty][tx] = s1;
+    __syncthreads();
+    if (ty == 0 && active) {
+        float4 a = red[0][0][tx], b = red[1][0][tx];
+        for (int k = 1; k < 4; ++k) {
+            const float4 u = red[0][k][tx], v = red[1][k][tx];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        if (MODE == 0) {
+            atomicAdd(p.out0 + c + 0, a.x); atomicAdd(p.out0 + c + 1, a.y);
+            atomicAdd(p.out0 + c + 2, a.z); atomicAdd(p.out0 + c + 3, a.w);
+        } else {
+            atomicAdd(p.dstat + c + 0, (double)a.x); atomicAdd(p.dstat + c + 1, (double)a.y);
+            atomicAdd(p.dstat + c + 2, (double)a.z); atomicAdd(p.dstat + c + 3, (double)a.w);
+            atomicAdd(p.dstat + p.C + c + 0, (double)b.x); atomicAdd(p.dstat + p.C + c + 1, (double)b.y);
+            atomicAdd(p.dstat + p.C + c + 2, (double)b.z); atomicAdd(p.dstat + p.C + c + 3, (double)b.w);
+        }
+    }
+}
+
+static void col_reduce_grid(int M, int C, dim3& g, int& rpb) {
+    const int gx = cdiv(C, 256);
+    int gy = cdiv(2048, gx);
+    rpb = cdiv(M, gy);
+    if (rpb < 16) rpb = 16;
+    rpb = (rpb + 3) & ~3;
+    gy = cdiv(M, rpb);
+    g = dim3(gx, gy);
+}
+
+// =====================================================================================================
+// BatchNorm (tf.layers.batch_normalization, training mode; modules.py:101)
+// =====================================================================================================
+// stats double[2C] (sum, sumsq over M rows) -> mean, var(biased), rstd, scale=gamma*rstd, shift=beta-mean*scale
+__global__ void bn_finalize_k(const double* __restrict__ dstat, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ mean, float* __restrict__ var, float* __restrict__ rstd,
+                              float* __restrict__ scale, float* __restrict__ shift, int M, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = dstat[c] / M;
+    double v = dstat[C + c] / M - mu * mu;
+    if (v < 0.0) v = 0.0;
+    const float r = (float)(1.0 / sqrt(v + (double)eps));
+    mean[c] = (float)mu; var[c] = (float)v; rstd[c] = r;
+    const float s = gamma[c] * r;
+    scale[c] = s; shift[c] = beta[c] - (float)mu * s;
+}
+
+// inference-mode parameters from moving statistics
+__global__ void bn_infer_params_k(const float* __restrict__ mm, const float* __restrict__ mv, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(mv[c] + eps);
+    scale[c] = s; shift[c] = beta[c] - mm[c] * s;
+}
+
+// y = [maxpool2](x*scale + shift) [+ res]
+__global__ void bn_apply_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale, const float* __restrict__ shift,
+                           const float* __restrict__ res, int ldr, float* __restrict__ y, int ldy, int M, int C, int T, int pool) {
+    const int c4n = C / 4;
+    const long total = (long)M * c4n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long m = idx / c4n;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        float4 b = f4fma(*reinterpret_cast<const float4*>(x + m * ldx + c), sc, sh);
+        if (pool && (int)(m % T) != T - 1) {
+            const float4 bn = f4fma(*reinterpret_cast<const float4*>(x + (m + 1) * ldx + c), sc, sh);
+            b.x = fmaxf(b.x, bn.x); b.y = fmaxf(b.y, bn.y); b.z = fmaxf(b.z, bn.z); b.w = fmaxf(b.w, bn.w);
+        }
+        if (res) {
+            const float4 r = *reinterpret_cast<const float4*>(res + m * ldr + c);
+            b.x += r.x; b.y += r.y; b.z += r.z; b.w += r.w;
+        }
+        *reinterpret_cast<float4*>(y + m * ldy + c) = b;
+    }
+}
+
+// dx = gamma*rstd*(db - sum(db)/M - xhat*sum(db*xhat)/M), then the conv activation's mask (relu: x > 0).
+// Also emits dgamma = sum(db*xhat), dbeta = sum(db) (block 0 only, ADDED into the gradient buffers).
+struct BnBwd {
+    ColRed r;  // x, dy, mean, rstd, scale, shift, dstat (sums from col_reduce MODE 2), M, C, T, pool
+    const float* gamma; float* dgamma; float* dbeta; float* dx; int lddx; int relu;
+};
+__global__ void bn_bwd_apply_k(BnBwd p) {
+    const ColRed& q = p.r;
+    const int c4n = q.C / 4;
+    const long total = (long)q.M * c4n;
+    const float invM = 1.0f / (float)q.M;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long m = idx / c4n;
+        const float4 sc = *reinterpret_cast<const float4*>(q.scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(q.shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(q.mean + c);
+        const float4 rs = *reinterpret_cast<const float4*>(q.rstd + c);
+        const float4 xv = *reinterpret_cast<const float4*>(q.x + m * q.ldx + c);
+        const float4 g = bn_out_grad(q, m, c, xv, sc, sh);
+        const float sdb[4] = {(float)q.dstat[c], (float)q.dstat[c + 1], (float)q.dstat[c + 2], (float)q.dstat[c + 3]};
+        const float sdx[4] = {(float)q.dstat[q.C + c], (float)q.dstat[q.C + c + 1], (float)q.dstat[q.C + c + 2], (float)q.dstat[q.C + c + 3]};
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g.x, g.y, g.z, g.w};
+        const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w}, scs[4] = {sc.x, sc.y, sc.z, sc.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xs[k] - mus[k]) * rss[k];
+            float d = scs[k] * (gs[k] - sdb[k] * invM - xh * sdx[k] * invM);
+            if (p.relu && !(xs[k] > 0.0f)) d = 0.0f;
+            o[k] = d;
+        }
+        *reinterpret_cast<float4*>(p.dx + m * p.lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < q.C; c += blockDim.x) {
+            p.dgamma[c] += (float)q.dstat[q.C + c];
+            p.dbeta[c] += (float)q.dstat[c];
+        }
+}
+
+// =====================================================================================================
+// Highway gating (modules.py:77-90).  Z = x.[W_H|W_T] + [b_H|b_T] is [M,256]; in place: Z <- [H, Tg]
+// =====================================================================================================
+__global__ void highway_gate_k(float* __restrict__ Z, const float* __restrict__ x, float* __restrict__ y, int M) {
+    const long total = (long)M * 32;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx & 31) * 4;
+        const long m = idx >> 5;
+        float4 h = *reinterpret_cast<float4*>(Z + m * 256 + c);
+        float4 t = *reinterpret_cast<float4*>(Z + m * 256 + 128 + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + m * 128 + c);
+        h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
+        t.x = sigmoidf_(t.x); t.y = sigmoidf_(t.y); t.z = sigmoidf_(t.z); t.w = sigmoidf_(t.w);
+        float4 o;
+        o.x = h.x * t.x + xv.x * (1.f - t.x); o.y = h.y * t.y + xv.y * (1.f - t.y);
+        o.z = h.z * t.z + xv.z * (1.f - t.z); o.w = h.w * t.w + xv.w * (1.f - t.w);
+        *reinterpret_cast<float4*>(Z + m * 256 + c) = h;
+        *reinterpret_cast<float4*>(Z + m * 256 + 128 + c) = t;
+        *reinterpret_cast<float4*>(y + m * 128 + c) = o;
+    }
+}
+
+// dZ = [dy*Tg*(H>0), dy*(H-x)*Tg*(1-Tg)];  dx_direct = dy*(1-Tg)
+__global__ void highway_gate_bwd_k(const float* __restrict__ HT, const float* __restrict__ x, const float* __restrict__ dy,
+                                   float* __restrict__ dZ, float* __restrict__ dx, int M) {
+    const long total = (long)M * 32;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx & 31) * 4;
+        const long m = idx >> 5;
+        const float4 h = *reinterpret_cast<const float4*>(HT + m * 256 + c);
+        const float4 t = *reinterpret_cast<const float4*>(HT + m * 256 + 128 + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + m * 128 + c);
+        const float4 g = *reinterpret_cast<const float4*>(dy + m * 128 + c);
+        float4 dh, dt, dd;
+        dh.x = h.x > 0.f ? g.x * t.x : 0.f; dh.y = h.y > 0.f ? g.y * t.y : 0.f;
+        dh.z = h.z > 0.f ? g.z * t.z : 0.f; dh.w = h.w > 0.f ? g.w * t.w : 0.f;
+        dt.x = g.x * (h.x - xv.x) * t.x * (1.f - t.x); dt.y = g.y * (h.y - xv.y) * t.y * (1.f - t.y);
+        dt.z = g.z * (h.z - xv.z) * t.z * (1.f - t.z); dt.w = g.w * (h.w - xv.w) * t.w * (1.f - t.w);
+        dd.x = g.x * (1.f - t.x); dd.y = g.y * (1.f - t.y); dd.z = g.z * (1.f - t.z); dd.w = g.w * (1.f - t.w);
+        *reinterpret_cast<float4*>(dZ + m * 256 + c) = dh;
+        *reinterpret_cast<float4*>(dZ + m * 256 + 128 + c) = dt;
+        *reinterpret_cast<float4*>(dx + m * 128 + c) = dd;
+    }
+}
+
+// relu backward on a dense layer output: dpre = y > 0 ? dy : 0  (in place allowed)
+__global__ void relu_bwd_k(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dpre, long n4) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const float4 yv = reinterpret_cast<const float4*>(y)[idx];
+        float4 g = reinterpret_cast<const float4*>(dy)[idx];
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        reinterpret_cast<float4*>(dpre)[idx] = g;
+    }
+}
+
+// y (+)= a + b  (b optional)
+__global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n4, int accumulate) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(a)[idx];
+        if (b) { const float4 w = reinterpret_cast<const float4*>(b)[idx]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        if (accumulate) { const float4 w = reinterpret_cast<const float4*>(y)[idx]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        reinterpret_cast<float4*>(y)[idx] = v;
+    }
+}
+
+// =====================================================================================================
+// L1 losses (models/tacotron.py:127-137) + sign gradients.  out/tgt [rows, C] with leading dims;
+// sums[0] += sum|d| over all columns, sums[1] += sum|d| over columns < npri;
+// grad[row, c] = sign(out - tgt) * (w_all + (c < npri ? w_pri : 0)); padded columns [C, ldg) get 0.
+// =====================================================================================================
+__global__ void l1_loss_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt, float* __restrict__ grad, int ldg,
+                          double* __restrict__ sums, long rows, int C, int npri, float w_all, float w_pri) {
+    const long total = rows * ldg;
+    float s_all = 0.f, s_pri = 0.f;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % ldg);
+        const long r = idx / ldg;
+        float g = 0.f;
+        if (c < C) {
+            const float d = out[r * ldo + c] - tgt[r * ldt + c];
+            const float a = fabsf(d);
+            s_all += a;
+            float w = w_all;
+            if (c < npri) { s_pri += a; w += w_pri; }
+            g = d > 0.f ? w : (d < 0.f ? -w : 0.f);
+        }
+        if (grad) grad[idx] = g;
+    }
+    const double a = wave_sum_d((double)s_all), b = wave_sum_d((double)s_pri);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(sums, a); atomicAdd(sums + 1, b); }
+}
+
+// =====================================================================================================
+// C-ABI wrappers
+// =====================================================================================================
+static inline int grid_for(long work_items, int block = 256) {
+    long g = (work_items + block - 1) / block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int taco_embed_gather_fwd(const int* ids, const int* identities, const float* table, const float* spk_table,
+                                     float* out, int N, int Ti, int Et, int Es, int vocab, int id_num, hipStream_t stream) {
+    if (!ids || !table || !out || (Et & 3) || (Es & 3) || (Es > 0 && (!identities || !spk_table))) return TACO_EINVAL;
+    const long total = (long)N * Ti * ((Et + Es) / 4);
+    hipLaunchKernelGGL(embed_gather_k, dim3(grid_for(total)), dim3(256), 0, stream, ids, identities, table, spk_table, out,
+                       N, Ti, Et, Es, vocab, id_num);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_embed_scatter_bwd(const int* ids, const int* identities, const float* dE, float* dTable, float* dSpk,
+                                      double* sparse_sumsq, int N, int Ti, int Et, int Es, int vocab, int id_num,
+                                      hipStream_t stream) {
+    if (!ids || !dE || !dTable || (Et & 3) || (Es & 3)) return TACO_EINVAL;
+    const long total = (long)N * Ti * (Et / 4);
+    hipLaunchKernelGGL(embed_scatter_text_k, dim3(grid_for(total)), dim3(256), 0, stream, ids, dE, dTable, sparse_sumsq,
+                       N * Ti, Et, Et + Es, vocab);
+    if (Es > 0) {
+        if (!identities || !dSpk || Es > 256 || 256 % Es) return TACO_EINVAL;
+        hipLaunchKernelGGL(embed_scatter_spk_k, dim3(N), dim3(256), 0, stream, identities, dE, dSpk, sparse_sumsq, Ti, Et, Es, id_num);
+    }
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_col_sum(const float* x, int ldx, float* out, int M, int C, hipStream_t stream) {
+    if (!x || !out || (C & 3) || (ldx & 3)) return TACO_EINVAL;
+    ColRed p{}; p.x = x; p.ldx = ldx; p.out0 = out; p.M = M; p.C = C; p.T = M;
+    dim3 g; col_reduce_grid(M, C, g, p.rows_per_block);
+    hipLaunchKernelGGL(col_reduce_k<0>, g, dim3(256), 0, stream, p);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_bn_stats_fwd(const float* x, int ldx, const float* gamma, const float* beta, double* dstat_zeroed,
+                                 float* mean, float* var, float* rstd, float* scale, float* shift, int M, int C, float eps,
+                                 hipStream_t stream) {
+    if (!x || !dstat_zeroed || (C & 3) || (ldx & 3)) return TACO_EINVAL;
+    ColRed p{}; p.x = x; p.ldx = ldx; p.dstat = dstat_zeroed; p.M = M; p.C = C; p.T = M;
+    dim3 g; col_reduce_grid(M, C, g, p.rows_per_block);
+    hipLaunchKernelGGL(col_reduce_k<1>, g, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, stream, dstat_zeroed, gamma, beta, mean, var, rstd, scale, shift, M, C, eps);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_bn_infer_params(const float* moving_mean, const float* moving_var, const float* gamma, const float* beta,
+                                    float* scale, float* shift, int C, float eps, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_infer_params_k, dim3(cdiv(C, 256)), dim3(256), 0, stream, moving_mean, moving_var, gamma, beta, scale, shift, C, eps);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_bn_apply_fwd(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldr,
+                                 float* y, int ldy, int M, int C, int T, int pool, hipStream_t stream) {
+    if (!x || !y || (C & 3) || (ldx & 3) || (ldy & 3) || (res && (ldr & 3)) || M % T) return TACO_EINVAL;
+    hipLaunchKernelGGL(bn_apply_k, dim3(grid_for((long)M * C / 4)), dim3(256), 0, stream, x, ldx, scale, shift, res, ldr, y, ldy, M, C, T, pool);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_bn_bwd(const float* x, int ldx, const float* dy, int lddy, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, const float* gamma, double* dstat_zeroed, float* dgamma,
+                           float* dbeta, float* dx, int lddx, int M, int C, int T, int pool, int relu, hipStream_t stream) {
+    if (!x || !dy || !dx || !dstat_zeroed || (C & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || M % T) return TACO_EINVAL;
+    BnBwd b{};
+    ColRed& p = b.r;
+    p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy; p.mean = mean; p.rstd = rstd; p.scale = scale; p.shift = shift;
+    p.dstat = dstat_zeroed; p.M = M; p.C = C; p.T = T; p.pool = pool;
+    dim3 g; col_reduce_grid(M, C, g, p.rows_per_block);
+    hipLaunchKernelGGL(col_reduce_k<2>, g, dim3(256), 0, stream, p);
+    b.gamma = gamma; b.dgamma = dgamma; b.dbeta = dbeta; b.dx = dx; b.lddx = lddx; b.relu = relu;
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(grid_for((long)M * C / 4)), dim3(256), 0, stream, b);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_highway_gate_fwd(float* Z, const float* x, float* y, int M, hipStream_t stream) {
+    hipLaunchKernelGGL(highway_gate_k, dim3(grid_for((long)M * 32)), dim3(256), 0, stream, Z, x, y, M);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_highway_gate_bwd(const float* HT, const float* x, const float* dy, float* dZ, float* dx, int M, hipStream_t stream) {
+    hipLaunchKernelGGL(highway_gate_bwd_k, dim3(grid_for((long)M * 32)), dim3(256), 0, stream, HT, x, dy, dZ, dx, M);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_relu_bwd(const float* y, const float* dy, float* dpre, long n, hipStream_t stream) {
+    if (n & 3) return TACO_EINVAL;
+    hipLaunchKernelGGL(relu_bwd_k, dim3(grid_for(n / 4)), dim3(256), 0, stream, y, dy, dpre, n / 4);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_add(const float* a, const float* b, float* y, long n, int accumulate, hipStream_t stream) {
+    if (n & 3) return TACO_EINVAL;
+    hipLaunchKernelGGL(add_k, dim3(grid_for(n / 4)), dim3(256), 0, stream, a, b, y, n / 4, accumulate);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2,
+                            long rows, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
+    if (!out || !tgt || !sums2 || ldg < C) return TACO_EINVAL;
+    hipLaunchKernelGGL(l1_loss_k, dim3(grid_for(rows * ldg)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
+    TACO_RETURN_LAST();
+}

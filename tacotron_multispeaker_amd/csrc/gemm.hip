@@ -1,0 +1,448 @@
+// fp32 MFMA implicit-GEMM kernels for gfx950: dense layers and 'same'-padded conv1d (incl. the fused
+// CBHG conv bank) forward, input-gradient and weight-gradient.
+//
+// Reference ops replaced: tf.layers.dense / tf.layers.conv1d at models/modules.py:10,79-89,95-100 and
+// models/tacotron.py:101, plus their TF-generated gradients (optimizer.compute_gradients, tacotron.py:187).
+//
+// Layout: activations are channel-last [N*T, C] row-major exactly like the reference tensors [N,T,C];
+// conv kernels are TF layout [k, Cin, Cout].  A conv tap j is a GEMM over rows shifted by j-pad_left
+// inside each length-T sequence (zeros outside) -> no im2col buffer is ever materialised.
+//
+// Math: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains, 256 FLOP/clk/CU = 157 TFLOP/s chip peak).
+// 4 waves per workgroup in a 2x2 arrangement; tiles are staged through LDS with register double
+// buffering (global loads of tile s+1 are in flight while tile s is multiplied).
+#include "common.hpp"
+
+struct ConvGemm {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;        // NN/NT: M rows, N output cols, K reduction per tap.  TN: M reduction rows, K x N output
+    int lda, ldb, ldc;
+    int T;              // sequence length (rows m = n*T + t) for the tap-shift mask
+    int kw_lo, kw_hi;   // conv widths iterated (plain: kw_lo == kw_hi == k; dense: 1; bank dX: 1..Kbank)
+    int bank;           // conv-bank addressing (weights packed [sum k][Cin][cpb], outputs concatenated)
+    int cpb;            // channels per bank conv (128)
+    int act;            // NN epilogue activation
+    int accumulate;     // NN/NT: C += result
+    int splitk;         // TN: reduction split
+    int shift0;         // TN: extra row shift of X (dW of recurrent weights: X = H shifted by one step)
+};
+
+// ---- MFMA inner product on one staged K-tile -------------------------------------------------------
+// A tile: k-contiguous [BM][BK+4] (AKC) or k-strided [BK][BM];  B tile likewise with BN.
+// k permutation: within an 8-wide chunk, MFMA q of lane-half h consumes k = 8*kk + 4*h + q for BOTH
+// operands, so a k-contiguous operand is fetched with one ds_read_b128 per 4 MFMAs.
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
+                                         f32x16 (&acc)[BM / 64][BN / 64], int wm, int wn, int lane) {
+    constexpr int MI = BM / 64, NI = BN / 64, LDK = BK + 4;
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+        float a[MI][4], b[NI][4];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * (BM / 2) + mi * 32 + i;
+            if (AKC) {
+                const float4 v = *reinterpret_cast<const float4*>(&As[row * LDK + kk * 8 + 4 * h]);
+                a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[mi][q] = As[(kk * 8 + 4 * h + q) * BM + row];
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = wn * (BN / 2) + ni * 32 + i;
+            if (BKC) {
+                const float4 v = *reinterpret_cast<const float4*>(&Bs[col * LDK + kk * 8 + 4 * h]);
+                b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[ni][q] = Bs[(kk * 8 + 4 * h + q) * BN + col];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][q], b[ni][q], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// ---- tile loaders (global -> registers, registers -> LDS) --------------------------------------------
+// k-contiguous tile [ROWS][BK]: thread owns float4 #(tid + v*256); BK/4 float4 per row
+template <int ROWS, int BK>
+struct KC {
+    static constexpr int NV = ROWS * BK / 4 / 256;
+    static constexpr int TPR = BK / 4;
+    static constexpr int LDK = BK + 4;
+    __device__ static __forceinline__ int row(int tid, int v) { return (tid + v * 256) / TPR; }
+    __device__ static __forceinline__ int c4(int tid, int v) { return (tid + v * 256) % TPR; }
+    __device__ static __forceinline__ void store(float* s, int tid, const float4 (&r)[NV]) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            *reinterpret_cast<float4*>(&s[row(tid, v) * LDK + c4(tid, v) * 4]) = r[v];
+    }
+};
+// k-strided tile [BK][COLS]
+template <int COLS, int BK>
+struct KS {
+    static constexpr int NV = COLS * BK / 4 / 256;
+    static constexpr int TPR = COLS / 4;
+    __device__ static __forceinline__ int row(int tid, int v) { return (tid + v * 256) / TPR; }
+    __device__ static __forceinline__ int c4(int tid, int v) { return (tid + v * 256) % TPR; }
+    __device__ static __forceinline__ void store(float* s, int tid, const float4 (&r)[NV]) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            *reinterpret_cast<float4*>(&s[row(tid, v) * COLS + c4(tid, v) * 4]) = r[v];
+    }
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, bool ok) {
+    return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- epilogue: 32x32 accumulator -> C (row-major), lane = column, registers = rows --------------------
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_store(const ConvGemm& p, f32x16 (&acc)[BM / 64][BN / 64], int m0, int n0,
+                                               int wm, int wn, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < BN / 64; ++ni) {
+        const int col = n0 + wn * (BN / 2) + ni * 32 + i;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < BM / 64; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.M) {
+                    float* c = p.C + (long)row * p.ldc + col;
+                    float v = apply_act(acc[mi][ni][r] + bv, p.act);
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// NN: C[m,n] = act(bias[n] + sum_j sum_c A[m + j - pl, c] * W[j][c][n])        (forward dense/conv/bank)
+// =====================================================================================================
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void conv_gemm_nn(ConvGemm p) {
+    using TA = KC<BM, BK>;
+    using TB = KS<BN, BK>;
+    __shared__ __attribute__((aligned(16))) float smem[2][BM * (BK + 4) + BK * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int by = p.bank ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;  // bank: widest convs first
+    const int n0 = by * BN;
+
+    int kw = p.kw_lo, ldb = p.ldb, nloc0 = n0, nlim = p.N;
+    const float* Bb = p.B;
+    if (p.bank) {
+        kw = 1 + n0 / p.cpb;
+        Bb = p.B + (long)p.K * p.cpb * ((kw - 1) * kw / 2);
+        ldb = p.cpb;
+        nloc0 = n0 - (kw - 1) * p.cpb;
+        nlim = p.cpb;
+    }
+    const int pl = (kw - 1) / 2;
+    const int ksteps = (p.K + BK - 1) / BK;
+    const int nsteps = kw * ksteps;
+
+    int tpos[TA::NV];
+#pragma unroll
+    for (int v = 0; v < TA::NV; ++v) tpos[v] = (m0 + TA::row(tid, v)) % p.T;
+
+    f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < BN / 64; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    float4 ra[TA::NV], rb[TB::NV];
+    auto gload = [&](int s) {
+        const int j = s / ksteps, kc = s - j * ksteps;
+        const int shift = j - pl;
+#pragma unroll
+        for (int v = 0; v < TA::NV; ++v) {
+            const int grow = m0 + TA::row(tid, v);
+            const int k = kc * BK + TA::c4(tid, v) * 4;
+            const bool ok = grow < p.M && k < p.K && (unsigned)(tpos[v] + shift) < (unsigned)p.T;
+            ra[v] = ld4(p.A + (long)(grow + shift) * p.lda + k, ok);
+        }
+        const float* Wj = Bb + (long)j * p.K * ldb;
+#pragma unroll
+        for (int v = 0; v < TB::NV; ++v) {
+            const int k = kc * BK + TB::row(tid, v);
+            const int n = nloc0 + TB::c4(tid, v) * 4;
+            rb[v] = ld4(Wj + (long)k * ldb + n, k < p.K && n < nlim);
+        }
+    };
+
+    gload(0);
+    TA::store(smem[0], tid, ra);
+    TB::store(smem[0] + BM * (BK + 4), tid, rb);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        mma_tile<BM, BN, BK, true, false>(smem[cur], smem[cur] + BM * (BK + 4), acc, wm, wn, lane);
+        if (s + 1 < nsteps) {
+            TA::store(smem[cur ^ 1], tid, ra);
+            TB::store(smem[cur ^ 1] + BM * (BK + 4), tid, rb);
+        }
+        __syncthreads();
+    }
+    epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// =====================================================================================================
+// NT: C[m,c] (+)= sum_kw sum_j sum_n dY[m - (j - pl), aoff(kw) + n] * W_kw[j][c][n]      (input gradient)
+//     here p.N = Cin (output cols), p.K = Cout per conv (reduction per tap)
+// =====================================================================================================
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
+    using TA = KC<BM, BK>;
+    using TB = KC<BN, BK>;
+    __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * (BK + 4)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ksteps = (p.K + BK - 1) / BK;
+
+    int tpos[TA::NV];
+#pragma unroll
+    for (int v = 0; v < TA::NV; ++v) tpos[v] = (m0 + TA::row(tid, v)) % p.T;
+
+    f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < BN / 64; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    // flattened (kw, j, kc) iteration state for the NEXT tile to load
+    int l_kw = p.kw_lo, l_j = 0, l_kc = 0;
+    int nsteps = 0;
+    for (int kw = p.kw_lo; kw <= p.kw_hi; ++kw) nsteps += kw * ksteps;
+
+    float4 ra[TA::NV], rb[TB::NV];
+    auto gload = [&]() {
+        const int kw = l_kw, j = l_j, kc = l_kc;
+        const int shift = -(j - (kw - 1) / 2);
+        const int aoff = p.bank ? (kw - 1) * p.cpb : 0;
+        const int ldb = p.bank ? p.cpb : p.ldb;
+        const float* Wj = (p.bank ? p.B + (long)p.N * p.cpb * ((kw - 1) * kw / 2) : p.B) + (long)j * p.N * ldb;
+#pragma unroll
+        for (int v = 0; v < TA::NV; ++v) {
+            const int grow = m0 + TA::row(tid, v);
+            const int k = kc * BK + TA::c4(tid, v) * 4;
+            const bool ok = grow < p.M && k < p.K && (unsigned)(tpos[v] + shift) < (unsigned)p.T;
+            ra[v] = ld4(p.A + (long)(grow + shift) * p.lda + aoff + k, ok);
+        }
+#pragma unroll
+        for (int v = 0; v < TB::NV; ++v) {
+            const int c = n0 + TB::row(tid, v);
+            const int k = kc * BK + TB::c4(tid, v) * 4;
+            rb[v] = ld4(Wj + (long)c * ldb + k, c < p.N && k < p.K);
+        }
+        if (++l_kc == ksteps) { l_kc = 0; if (++l_j == l_kw) { l_j = 0; ++l_kw; } }
+    };
+
+    gload();
+    TA::store(smem[0], tid, ra);
+    TB::store(smem[0] + BM * (BK + 4), tid, rb);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) gload();
+        mma_tile<BM, BN, BK, true, true>(smem[cur], smem[cur] + BM * (BK + 4), acc, wm, wn, lane);
+        if (s + 1 < nsteps) {
+            TA::store(smem[cur ^ 1], tid, ra);
+            TB::store(smem[cur ^ 1] + BM * (BK + 4), tid, rb);
+        }
+        __syncthreads();
+    }
+    epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// =====================================================================================================
+// TN: dW_kw[j][c][n] += sum_m X[m + j - pl, c] * dY[m, aoff(kw) + n]                     (weight gradient)
+//     p.M = reduction rows, p.K = Cin (output rows), p.N = Cout per conv (output cols);
+//     grid.z = segment(kw,j) * splitk + split; partial sums are atomically added into pre-zeroed C.
+// =====================================================================================================
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void conv_gemm_tn(ConvGemm p) {
+    using TA = KS<BM, BK>;
+    using TB = KS<BN, BK>;
+    __shared__ __attribute__((aligned(16))) float smem[2][BK * (BM + BN)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int c0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int seg = blockIdx.z / p.splitk;
+    const int split = blockIdx.z - seg * p.splitk;
+    int kw = p.kw_lo, j = seg;
+    if (p.bank) { kw = 1; while (seg >= kw) { seg -= kw; ++kw; } j = seg; }
+    const int shift = j - (kw - 1) / 2 + p.shift0;
+    const int aoff = p.bank ? (kw - 1) * p.cpb : 0;
+    const int ldc = p.bank ? p.cpb : p.ldc;
+    float* Cw = p.C + (p.bank ? (long)p.K * p.cpb * ((kw - 1) * kw / 2) : 0) + (long)j * p.K * ldc;
+
+    const int ktiles = (p.M + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt0 = split * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < BN / 64; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    float4 ra[TA::NV], rb[TB::NV];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int v = 0; v < TA::NV; ++v) {
+            const int m = kt * BK + TA::row(tid, v);
+            const int c = c0 + TA::c4(tid, v) * 4;
+            const bool ok = m < p.M && c < p.K && (unsigned)(m % p.T + shift) < (unsigned)p.T;
+            ra[v] = ld4(p.A + (long)(m + shift) * p.lda + c, ok);
+        }
+#pragma unroll
+        for (int v = 0; v < TB::NV; ++v) {
+            const int m = kt * BK + TB::row(tid, v);
+            const int n = n0 + TB::c4(tid, v) * 4;
+            rb[v] = ld4(p.B + (long)m * p.ldb + aoff + n, m < p.M && n < p.N);
+        }
+    };
+
+    gload(kt0);
+    TA::store(smem[0], tid, ra);
+    TB::store(smem[0] + BK * BM, tid, rb);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) gload(kt + 1);
+        mma_tile<BM, BN, BK, false, false>(smem[cur], smem[cur] + BK * BM, acc, wm, wn, lane);
+        if (kt + 1 < kt1) {
+            TA::store(smem[cur ^ 1], tid, ra);
+            TB::store(smem[cur ^ 1] + BK * BM, tid, rb);
+        }
+        __syncthreads();
+    }
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < BN / 64; ++ni) {
+        const int col = n0 + wn * (BN / 2) + ni * 32 + i;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.K) atomicAdd(Cw + (long)row * ldc + col, acc[mi][ni][r]);
+            }
+    }
+}
+
+// ---- host-side dispatch --------------------------------------------------------------------------------
+static bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int check_common(const ConvGemm& p) {
+    if (!p.A || !p.B || !p.C) return TACO_EINVAL;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.T <= 0) return TACO_EINVAL;
+    if (!aligned4(p.A) || !aligned4(p.B)) return TACO_EINVAL;
+    if ((p.lda & 3) || (p.ldb & 3)) return TACO_EINVAL;
+    return TACO_OK;
+}
+
+extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin,
+                                  int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate,
+                                  hipStream_t stream) {
+    // bank_K > 0: fused conv bank (widths 1..bank_K, 128 channels each, outputs concatenated: Cout = bank_K*128)
+    ConvGemm p{};
+    p.A = X; p.B = W; p.C = Y; p.bias = bias;
+    p.M = M; p.K = Cin; p.T = T; p.lda = ldx; p.ldc = ldy; p.act = act; p.accumulate = accumulate; p.splitk = 1;
+    if (bank_K > 0) { p.bank = 1; p.cpb = 128; p.N = bank_K * 128; p.ldb = 128; p.kw_lo = 1; p.kw_hi = bank_K; }
+    else { p.bank = 0; p.cpb = 0; p.N = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
+    if (int e = check_common(p)) return e;
+    if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(p.N, 128);
+    if (tiles128 >= 192) {
+        dim3 g(cdiv(M, 128), cdiv(p.N, 128));
+        hipLaunchKernelGGL((conv_gemm_nn<128, 128, 16>), g, dim3(256), 0, stream, p);
+    } else {
+        dim3 g(cdiv(M, 64), cdiv(p.N, 64));
+        hipLaunchKernelGGL((conv_gemm_nn<64, 64, 32>), g, dim3(256), 0, stream, p);
+    }
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* dX, int M, int T, int Cin, int Cout,
+                                       int kw, int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream) {
+    ConvGemm p{};
+    p.A = dY; p.B = W; p.C = dX; p.bias = nullptr;
+    p.M = M; p.N = Cin; p.T = T; p.lda = lddy; p.ldc = lddx; p.act = ACT_NONE; p.accumulate = accumulate; p.splitk = 1;
+    if (bank_K > 0) { p.bank = 1; p.cpb = 128; p.K = 128; p.ldb = 128; p.kw_lo = 1; p.kw_hi = bank_K; }
+    else { p.bank = 0; p.K = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
+    if (int e = check_common(p)) return e;
+    if (M % T != 0 || kw < 1) return TACO_EINVAL;
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(p.N, 128);
+    if (tiles128 >= 192) {
+        dim3 g(cdiv(M, 128), cdiv(p.N, 128));
+        hipLaunchKernelGGL((conv_gemm_nt<128, 128, 16>), g, dim3(256), 0, stream, p);
+    } else {
+        dim3 g(cdiv(M, 64), cdiv(p.N, 64));
+        hipLaunchKernelGGL((conv_gemm_nt<64, 64, 32>), g, dim3(256), 0, stream, p);
+    }
+    TACO_RETURN_LAST();
+}
+
+static int conv_gemm_bwd_weight_impl(const float* X, const float* dY, float* dW, int M, int T, int Cin, int Cout,
+                                     int kw, int bank_K, int ldx, int lddy, int ldw, int shift0, hipStream_t stream) {
+    // dW must be zero-initialised (or hold a running sum): partial sums are atomically ADDED.
+    ConvGemm p{};
+    p.shift0 = shift0;
+    p.A = X; p.B = dY; p.C = dW; p.bias = nullptr;
+    p.M = M; p.K = Cin; p.T = T; p.lda = ldx; p.ldb = lddy;
+    int nseg;
+    if (bank_K > 0) { p.bank = 1; p.cpb = 128; p.N = 128; p.ldc = 128; p.kw_lo = 1; p.kw_hi = bank_K; nseg = bank_K * (bank_K + 1) / 2; }
+    else { p.bank = 0; p.N = Cout; p.ldc = ldw; p.kw_lo = p.kw_hi = kw; nseg = kw; }
+    if (int e = check_common(p)) return e;
+    if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
+    const bool big = p.K >= 128 && p.N >= 128;
+    const int bm = big ? 128 : 64, bk = big ? 16 : 32;
+    const long tiles = (long)cdiv(p.K, bm) * cdiv(p.N, bm) * nseg;
+    const int ktiles = cdiv(M, bk);
+    int splitk = (int)((1024 + tiles - 1) / tiles);
+    const int max_split = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    if (splitk > max_split) splitk = max_split;
+    if (splitk < 1) splitk = 1;
+    p.splitk = splitk;
+    dim3 g(cdiv(p.K, bm), cdiv(p.N, bm), nseg * splitk);
+    if (big) hipLaunchKernelGGL((conv_gemm_tn<128, 128, 16>), g, dim3(256), 0, stream, p);
+    else     hipLaunchKernelGGL((conv_gemm_tn<64, 64, 32>), g, dim3(256), 0, stream, p);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_conv_gemm_bwd_weight(const float* X, const float* dY, float* dW, int M, int T, int Cin, int Cout,
+                                         int kw, int bank_K, int ldx, int lddy, int ldw, hipStream_t stream) {
+    return conv_gemm_bwd_weight_impl(X, dY, dW, M, T, Cin, Cout, kw, bank_K, ldx, lddy, ldw, 0, stream);
+}
+
+// dW[c,n] += sum_m X[m + shift, c] * dY[m, n] with rows outside the length-T sequence of m contributing zero
+// (shift = -1: X is a hidden-state sequence and dW the gradient of a recurrent weight)
+extern "C" int taco_gemm_tn_shift(const float* X, const float* dY, float* dW, int M, int T, int K, int N, int ldx, int lddy,
+                                  int ldw, int shift, hipStream_t stream) {
+    return conv_gemm_bwd_weight_impl(X, dY, dW, M, T, K, N, 1, 0, ldx, lddy, ldw, shift, stream);
+}

@@ -1,0 +1,105 @@
+// Optimizer of the Tacotron training step for gfx950: global-norm clip + TF-style Adam + Noam learning rate
+// over ONE flat fp32 parameter buffer (multi-tensor by construction), and batch-norm moving statistics.
+// Reference: models/tacotron.py:174-202 (tf.train.AdamOptimizer, tf.clip_by_global_norm(.,1.0),
+// _learning_rate_decay, UPDATE_OPS); TF semantics SURVEY Appendix A.4, A.10, A.11.
+// HBM-bound: 28 B read + 12 B written per parameter.  global_step lives on the device so that a whole
+// training step can be replayed from a HIP graph without any host-side scalar.
+#include "common.hpp"
+
+__global__ void sumsq_k(const float* __restrict__ x, long n4, long n, double* __restrict__ acc) {
+    float s = 0.0f;
+    double d = 0.0;
+    int cnt = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        if (++cnt == 64) { d += (double)s; s = 0.0f; cnt = 0; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n4 * 4 + threadIdx.x]; s += v * v; }
+    d += (double)s;
+    d = wave_sum_d(d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, d);
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; long n4;
+    const double* gnorm2; const int* step;
+    float init_lr, beta1, beta2, eps, clip; int decay;
+    float* info;     // optional [3]: global_norm, learning_rate, scale (written by thread 0)
+};
+
+__global__ void adam_k(AdamArgs a) {
+    const double t = (double)(*a.step + 1);
+    double lr = a.init_lr;
+    if (a.decay) lr = (double)a.init_lr * sqrt(4000.0) * fmin(t * pow(4000.0, -1.5), 1.0 / sqrt(t));   // tacotron.py:198-202
+    const float lr_t = (float)(lr * sqrt(1.0 - pow((double)a.beta2, t)) / (1.0 - pow((double)a.beta1, t)));
+    const float norm = (float)sqrt(*a.gnorm2);
+    const float scale = a.clip / fmaxf(norm, a.clip);      // tf.clip_by_global_norm
+    if (a.info && blockIdx.x == 0 && threadIdx.x == 0) { a.info[0] = norm; a.info[1] = (float)lr; a.info[2] = scale; }
+    const float b1 = a.beta1, b2 = a.beta2, eps = a.eps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.n4; i += (long)gridDim.x * blockDim.x) {
+        float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
+        m.x = b1 * m.x + (1.f - b1) * g.x; m.y = b1 * m.y + (1.f - b1) * g.y; m.z = b1 * m.z + (1.f - b1) * g.z; m.w = b1 * m.w + (1.f - b1) * g.w;
+        v.x = b2 * v.x + (1.f - b2) * g.x * g.x; v.y = b2 * v.y + (1.f - b2) * g.y * g.y;
+        v.z = b2 * v.z + (1.f - b2) * g.z * g.z; v.w = b2 * v.w + (1.f - b2) * g.w * g.w;
+        p.x -= lr_t * m.x / (sqrtf(v.x) + eps); p.y -= lr_t * m.y / (sqrtf(v.y) + eps);
+        p.z -= lr_t * m.z / (sqrtf(v.z) + eps); p.w -= lr_t * m.w / (sqrtf(v.w) + eps);
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        reinterpret_cast<float4*>(a.p)[i] = p;
+    }
+}
+
+__global__ void bn_ema_k(float* __restrict__ mov, const float* __restrict__ batch, int n, float momentum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mov[i] -= (mov[i] - batch[i]) * (1.0f - momentum);
+}
+
+__global__ void step_inc_k(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+
+__global__ void scale_k(float* __restrict__ x, long n4, float s) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+}
+
+extern "C" int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream) {
+    if (!x || !acc || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return TACO_EINVAL;
+    const long n4 = n / 4;
+    long g = (n4 + 255) / 256; if (g > 1024) g = 1024; if (g < 1) g = 1;
+    hipLaunchKernelGGL(sumsq_k, dim3((int)g), dim3(256), 0, stream, x, n4, n, acc);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_adam_step(float* params, const float* grads, float* m, float* v, long n, const double* gnorm2,
+                              const int* global_step, float init_lr, int decay, float beta1, float beta2, float eps, float clip,
+                              float* info3, hipStream_t stream) {
+    if (!params || !grads || !m || !v || !gnorm2 || !global_step || (n & 3)) return TACO_EINVAL;
+    AdamArgs a{params, grads, m, v, n / 4, gnorm2, global_step, init_lr, beta1, beta2, eps, clip, decay, info3};
+    long g = (a.n4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(adam_k, dim3((int)g), dim3(256), 0, stream, a);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_bn_ema(float* moving, const float* batch, int n, float momentum, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_ema_k, dim3(cdiv(n, 256)), dim3(256), 0, stream, moving, batch, n, momentum);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_step_inc(int* global_step, hipStream_t stream) {
+    hipLaunchKernelGGL(step_inc_k, dim3(1), dim3(64), 0, stream, global_step);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_scale(float* x, long n, float s, hipStream_t stream) {
+    if (n & 3) return TACO_EINVAL;
+    long g = (n / 4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(scale_k, dim3((int)g), dim3(256), 0, stream, x, n / 4, s);
+    TACO_RETURN_LAST();
+}

@@ -1,0 +1,437 @@
+"""Host-side driver of the MI355X Tacotron training step: owns the flat parameter / gradient / Adam buffers
+and the activation workspace (torch tensors = device memory only) and sequences the HIP kernels of
+libtaco_hip.so (C-ABI, include/taco_hip.h) on the current HIP stream.  No torch compute op is on the path:
+forward, backward and the optimizer are hand-written kernels; everything is asynchronous and free of
+host<->device synchronisation, so a full step can be captured into a HIP graph (Engine.capture_step).
+
+Reference being replaced: the TF-1 graph built by models/tacotron.py:35-195 and run at train.py:142-146.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from ._lib import lib
+from .params import ParamLayout, init_named
+
+BN_EPS = 1e-3        # tf.layers.batch_normalization defaults
+BN_MOMENTUM = 0.99
+
+ACT_NONE, ACT_RELU = 0, 1
+
+# slots of the attention pointer table (enum TacoAttnPtr in include/taco_hip.h)
+_AP = ['W1C', 'F1', 'W2', 'B2', 'WX', 'WHG', 'WHC', 'BG', 'WQ', 'V', 'KEYS', 'MEM', 'ZEROS', 'P1', 'P2', 'R', 'U', 'C',
+       'RH', 'HC', 'Q', 'ALIGN', 'DHC', 'DXP', 'DP2', 'DP1', 'DQ', 'DKEYS', 'DMEM', 'DVPART', 'DA', 'DHT', 'DHPART',
+       'DHCARRY', 'DCTX', 'DCTXCARRY']
+AP = {n: i for i, n in enumerate(_AP)}
+
+
+class Engine:
+    def __init__(self, vocab=7352, embed_text=256, embed_id=64, id_num=0, r=5, num_mels=80, num_freq=1025,
+                 sample_rate=20000, init_lr=0.002, decay_lr=True, beta1=0.9, beta2=0.999, tf_sparse_norm=True,
+                 device='cuda', seed=0, named_params=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('tacotron_multispeaker_amd.Engine needs an MI355X (HIP) device; there is no CPU path')
+        lib.load()
+        self.dev = torch.device(device)
+        self.L = ParamLayout(vocab, embed_text, embed_id, id_num, r, num_mels, num_freq)
+        L = self.L
+        self.r, self.nm, self.nf = r, num_mels, num_freq
+        self.npri = int(3000 / (sample_rate * 0.5) * num_freq)       # tacotron.py:134
+        self.init_lr, self.decay_lr, self.beta1, self.beta2 = init_lr, decay_lr, beta1, beta2
+        self.tf_sparse_norm = tf_sparse_norm
+        f = dict(dtype=torch.float32, device=self.dev)
+        self.params = torch.zeros(L.total, **f)
+        self.grads = torch.zeros(L.total, **f)
+        self.m = torch.zeros(L.total, **f)
+        self.v = torch.zeros(L.total, **f)
+        self.bn = torch.zeros(max(L.bn_total, 4), **f)              # moving mean / variance
+        self.bnbatch = torch.zeros(max(L.bn_total, 4), **f)         # batch mean / variance of the last step
+        self.global_step = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.dscratch = torch.zeros(1 << 16, dtype=torch.float64, device=self.dev)   # zeroed once per step
+        self.info = torch.zeros(4, **f)
+        self._bufs = {}
+        self._dpos = 0
+        self.world = 1
+        self.load_named(named_params if named_params is not None else init_named(L, seed))
+
+    # ---- parameters ---------------------------------------------------------------------------------------
+    def load_named(self, named):
+        cpu = torch.zeros(self.L.total, dtype=torch.float32)
+        cpubn = torch.zeros(max(self.L.bn_total, 4), dtype=torch.float32)
+        self.L.load_named(named, cpu, cpubn)
+        self.params.copy_(cpu)
+        self.bn.copy_(cpubn)
+
+    def export_named(self, which='params'):
+        flat = {'params': self.params, 'grads': self.grads, 'm': self.m, 'v': self.v}[which]
+        return self.L.export_named(flat, self.bn if which == 'params' else None)
+
+    def P(self, name):
+        return self.L.view(self.params, name)
+
+    def G(self, name):
+        return self.L.view(self.grads, name)
+
+    # ---- workspace ------------------------------------------------------------------------------------------
+    def buf(self, name, *shape, dtype=torch.float32):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.zeros(*shape, dtype=dtype, device=self.dev)
+            self._bufs[name] = t
+        return t
+
+    def dslot(self, n):
+        """n doubles of per-step zeroed reduction scratch."""
+        n = (n + 1) & ~1
+        if self._dpos + n > self.dscratch.numel():
+            raise RuntimeError('double scratch exhausted')
+        s = self.dscratch[self._dpos:self._dpos + n]
+        self._dpos += n
+        return s
+
+    @property
+    def st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- op helpers ---------------------------------------------------------------------------------------------
+    def gemm(self, X, W, bias, Y, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, ldw=None, ldy=None, act=0, acc=0):
+        lib.taco_conv_gemm_fwd(X, W, bias, Y, M, T or M, Cin, Cout, kw, bank,
+                               ldx or X.stride(-2), ldw or Cout, ldy or Y.stride(-2), act, acc, self.st)
+
+    def gemm_dx(self, dY, W, dX, M, Cin, Cout, T=None, kw=1, bank=0, lddy=None, ldw=None, lddx=None, acc=0):
+        lib.taco_conv_gemm_bwd_data(dY, W, dX, M, T or M, Cin, Cout, kw, bank,
+                                    lddy or dY.stride(-2), ldw or Cout, lddx or dX.stride(-2), acc, self.st)
+
+    def gemm_dw(self, X, dY, dW, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, lddy=None, ldw=None):
+        lib.taco_conv_gemm_bwd_weight(X, dY, dW, M, T or M, Cin, Cout, kw, bank,
+                                      ldx or X.stride(-2), lddy or dY.stride(-2), ldw or Cout, self.st)
+
+    def gemm_dw_shift(self, X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift=-1):
+        lib.taco_gemm_tn_shift(X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift, self.st)
+
+    def colsum(self, x, out, M, C, ldx=None):
+        lib.taco_col_sum(x, ldx or x.stride(-2), out, M, C, self.st)
+
+    def dense_fwd(self, x, scope, y, M, cin, cout, act=0):
+        self.gemm(x, self.P(scope + '/kernel'), self.P(scope + '/bias'), y, M, cin, cout, act=act)
+
+    def dense_bwd(self, x, dy, scope, M, cin, cout, dx=None, acc=0):
+        """dy = gradient wrt the layer's pre-activation."""
+        self.gemm_dw(x, dy, self.G(scope + '/kernel'), M, cin, cout)
+        self.colsum(dy, self.G(scope + '/bias'), M, cout)
+        if dx is not None:
+            self.gemm_dx(dy, self.P(scope + '/kernel'), dx, M, cin, cout, acc=acc)
+
+    # ---- conv + BN ------------------------------------------------------------------------------------------------
+    def bn_fwd(self, scope, x, M, C, training):
+        sc, sh = self.buf(scope + '/bn_scale', C), self.buf(scope + '/bn_shift', C)
+        if training:
+            lib.taco_bn_stats_fwd(x, x.stride(-2), self.P(scope + '/gamma'), self.P(scope + '/beta'), self.dslot(2 * C),
+                                  self.L.bnview(self.bnbatch, scope + '/moving_mean'),
+                                  self.L.bnview(self.bnbatch, scope + '/moving_variance'),
+                                  self.buf(scope + '/bn_rstd', C), sc, sh, M, C, BN_EPS, self.st)
+        else:
+            lib.taco_bn_infer_params(self.L.bnview(self.bn, scope + '/moving_mean'),
+                                     self.L.bnview(self.bn, scope + '/moving_variance'),
+                                     self.P(scope + '/gamma'), self.P(scope + '/beta'), sc, sh, C, BN_EPS, self.st)
+        return sc, sh
+
+    def bn_bwd(self, scope, x, dy, dx, M, C, T, pool, relu):
+        lib.taco_bn_bwd(x, x.stride(-2), dy, dy.stride(-2), self.L.bnview(self.bnbatch, scope + '/moving_mean'),
+                        self.buf(scope + '/bn_rstd', C), self.buf(scope + '/bn_scale', C), self.buf(scope + '/bn_shift', C),
+                        self.P(scope + '/gamma'), self.dslot(2 * C), self.G(scope + '/gamma'), self.G(scope + '/beta'),
+                        dx, dx.stride(-2), M, C, T, pool, relu, self.st)
+
+    # ---- CBHG (models/modules.py:35-74) ----------------------------------------------------------------------------
+    def cbhg_fwd(self, sc, x, N, T, cin, K, proj, lengths, training):
+        M, C, st = N * T, K * 128, self.st
+        B = self.buf(sc + '/bank', M, C)
+        self.gemm(x, self.P(sc + '/conv_bank/kernel'), self.P(sc + '/conv_bank/bias'), B, M, cin, C, T=T, kw=K, bank=K,
+                  ldw=128, act=ACT_RELU)
+        s, h = self.bn_fwd(sc + '/conv_bank', B, M, C, training)
+        PL = self.buf(sc + '/pool', M, C)
+        lib.taco_bn_apply_fwd(B, C, s, h, None, 0, PL, C, M, C, T, 1, st)
+        C1 = self.buf(sc + '/c1', M, proj[0])
+        self.gemm(PL, self.P(sc + '/proj_1/kernel'), self.P(sc + '/proj_1/bias'), C1, M, C, proj[0], T=T, kw=3, act=ACT_RELU)
+        s, h = self.bn_fwd(sc + '/proj_1', C1, M, proj[0], training)
+        Y1 = self.buf(sc + '/y1', M, proj[0])
+        lib.taco_bn_apply_fwd(C1, proj[0], s, h, None, 0, Y1, proj[0], M, proj[0], T, 0, st)
+        C2 = self.buf(sc + '/c2', M, proj[1])
+        self.gemm(Y1, self.P(sc + '/proj_2/kernel'), self.P(sc + '/proj_2/bias'), C2, M, proj[0], proj[1], T=T, kw=3)
+        s, h = self.bn_fwd(sc + '/proj_2', C2, M, proj[1], training)
+        HW0 = self.buf(sc + '/hw0', M, proj[1])
+        lib.taco_bn_apply_fwd(C2, proj[1], s, h, x, cin, HW0, proj[1], M, proj[1], T, 0, st)   # + residual
+        hw = HW0
+        if proj[1] != 128:
+            hw = self.buf(sc + '/hwd', M, 128)
+            self.dense_fwd(HW0, sc + '/highway_dense', hw, M, proj[1], 128)
+        for i in range(1, 5):
+            Z = self.buf('%s/hwZ%d' % (sc, i), M, 256)
+            self.gemm(hw, self.P('%s/highway_%d/kernel' % (sc, i)), self.P('%s/highway_%d/bias' % (sc, i)), Z, M, 128, 256)
+            nxt = self.buf('%s/hw%d' % (sc, i), M, 128)
+            lib.taco_highway_gate_fwd(Z, hw, nxt, M, st)
+            hw = nxt
+        XP = self.buf(sc + '/xp', M, 768)
+        self.gemm(hw, self.P(sc + '/bigru/wx'), self.P(sc + '/bigru/bias'), XP, M, 128, 768)
+        OUT = self.buf(sc + '/out', M, 256)
+        RUC = self.buf(sc + '/ruc', 2, N, T, 384)
+        lib.taco_gru128_seq_fwd(XP, 768, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
+                                self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC, N, T, 2, st)
+        return OUT
+
+    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx):
+        """dOUT [M,256] gradient wrt the CBHG output; writes the gradient wrt the CBHG input x into dx [M,cin]."""
+        M, C, st = N * T, K * 128, self.st
+        b = self._bufs
+        OUT, RUC = b[sc + '/out'], b[sc + '/ruc']
+        dXP = self.buf(sc + '/dxp', M, 768)
+        HP, RH = self.buf(sc + '/hp', 2, M, 128), self.buf(sc + '/rh', 2, M, 128)
+        lib.taco_gru128_seq_bwd(dOUT, 256, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
+                                self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC,
+                                dXP, 768, HP, RH, N, T, 2, st)
+        hw4 = b[sc + '/hw4']
+        self.gemm_dw(hw4, dXP, self.G(sc + '/bigru/wx'), M, 128, 768)
+        self.colsum(dXP, self.G(sc + '/bigru/bias'), M, 768)
+        for di, d in enumerate(('fw', 'bw')):
+            self.gemm_dw(HP[di], dXP[:, di * 384:], self.G('%s/bigru/%s_whg' % (sc, d)), M, 128, 256, ldx=128, lddy=768, ldw=256)
+            self.gemm_dw(RH[di], dXP[:, di * 384 + 256:], self.G('%s/bigru/%s_whc' % (sc, d)), M, 128, 128, ldx=128, lddy=768, ldw=128)
+        dhw = self.buf(sc + '/dhw_a', M, 128)
+        self.gemm_dx(dXP, self.P(sc + '/bigru/wx'), dhw, M, 128, 768)
+        dZ = self.buf(sc + '/dZ', M, 256)
+        other = self.buf(sc + '/dhw_b', M, 128)
+        for i in range(4, 0, -1):
+            hw_in = b['%s/hw%d' % (sc, i - 1)] if i > 1 else (b[sc + '/hwd'] if proj[1] != 128 else b[sc + '/hw0'])
+            lib.taco_highway_gate_bwd(b['%s/hwZ%d' % (sc, i)], hw_in, dhw, dZ, other, M, st)
+            self.gemm_dw(hw_in, dZ, self.G('%s/highway_%d/kernel' % (sc, i)), M, 128, 256)
+            self.colsum(dZ, self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
+            self.gemm_dx(dZ, self.P('%s/highway_%d/kernel' % (sc, i)), other, M, 128, 256, acc=1)
+            dhw, other = other, dhw
+        if proj[1] != 128:
+            dHW0 = self.buf(sc + '/dhw0', M, proj[1])
+            self.dense_bwd(b[sc + '/hw0'], dhw, sc + '/highway_dense', M, proj[1], 128, dx=dHW0)
+        else:
+            dHW0 = dhw
+        # proj_2 (no activation) -> proj_1 (relu) -> pooled bank (relu)
+        dC2 = self.buf(sc + '/dc2', M, proj[1])
+        self.bn_bwd(sc + '/proj_2', b[sc + '/c2'], dHW0, dC2, M, proj[1], T, 0, 0)
+        self.gemm_dw(b[sc + '/y1'], dC2, self.G(sc + '/proj_2/kernel'), M, proj[0], proj[1], T=T, kw=3)
+        self.colsum(dC2, self.G(sc + '/proj_2/bias'), M, proj[1])
+        dY1 = self.buf(sc + '/dy1', M, proj[0])
+        self.gemm_dx(dC2, self.P(sc + '/proj_2/kernel'), dY1, M, proj[0], proj[1], T=T, kw=3)
+        dC1 = self.buf(sc + '/dc1', M, proj[0])
+        self.bn_bwd(sc + '/proj_1', b[sc + '/c1'], dY1, dC1, M, proj[0], T, 0, 1)
+        self.gemm_dw(b[sc + '/pool'], dC1, self.G(sc + '/proj_1/kernel'), M, C, proj[0], T=T, kw=3)
+        self.colsum(dC1, self.G(sc + '/proj_1/bias'), M, proj[0])
+        dPL = self.buf(sc + '/dpool', M, C)
+        self.gemm_dx(dC1, self.P(sc + '/proj_1/kernel'), dPL, M, C, proj[0], T=T, kw=3)
+        dB = self.buf(sc + '/dbank', M, C)
+        self.bn_bwd(sc + '/conv_bank', b[sc + '/bank'], dPL, dB, M, C, T, 1, 1)
+        self.gemm_dw(x, dB, self.G(sc + '/conv_bank/kernel'), M, cin, C, T=T, kw=K, bank=K, ldw=128)
+        self.colsum(dB, self.G(sc + '/conv_bank/bias'), M, C)
+        self.gemm_dx(dB, self.P(sc + '/conv_bank/kernel'), dx, M, cin, C, T=T, kw=K, bank=K, ldw=128)
+        lib.taco_add(dx, dHW0, dx, M * cin, 0, st)        # residual connection (modules.py:56)
+        return dx
+
+    # ---- forward (models/tacotron.py:35-104) ------------------------------------------------------------------------
+    def forward(self, inputs, input_lengths, mel_targets, identities=None, training=True):
+        L, st = self.L, self.st
+        N, Ti = inputs.shape
+        To = mel_targets.shape[1]
+        r, nm = self.r, self.nm
+        assert To % r == 0, 'T_out must be a multiple of outputs_per_step (datafeeder_npy.py:179-181)'
+        S = To // r
+        self.dims = (N, Ti, To, S)
+        self._dpos = 0
+        self.dscratch.zero_()
+        self.inputs, self.input_lengths, self.mel_targets, self.identities = inputs, input_lengths, mel_targets, identities
+        E = L.Et + L.Es
+        Me, Mp, Ms = N * Ti, N * To, N * S
+        X0 = self.buf('emb', Me, E)
+        lib.taco_embed_gather_fwd(inputs, identities if L.Es else None, self.P('embedding'),
+                                  self.P('embedding_id') if L.Es else None, X0, N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
+        A1, A2 = self.buf('enc_p1', Me, 256), self.buf('enc_p2', Me, 128)
+        self.dense_fwd(X0, 'prenet/dense_1', A1, Me, E, 256, ACT_RELU)
+        self.dense_fwd(A1, 'prenet/dense_2', A2, Me, 256, 128, ACT_RELU)
+        ENC = self.cbhg_fwd('encoder_cbhg', A2, N, Ti, 128, 16, (128, 128), input_lengths, training)
+        # ---- decoder
+        KEYS = self.buf('keys', Me, 256)
+        self.gemm(ENC, self.P('attention/memory_layer/kernel'), None, KEYS, Me, 256, 256)
+        FR = self.buf('frames', Ms, nm)
+        lib.taco_gather_frames(mel_targets, FR, N, S, r, nm, st)
+        W1 = self.P('decoder_prenet/dense_1/kernel')
+        F1 = self.buf('F1', Ms, 256)
+        self.gemm(FR, W1, self.P('decoder_prenet/dense_1/bias'), F1, Ms, nm, 256)
+        z = self.buf('zeros', max(N, 32) * 256)
+        self._attn_ptrs = self._make_attn_ptrs(N, S, Ti)
+        lib.taco_attn_rnn_fwd(self._attn_ptrs, self._attn_dims, st)
+        HC = self._bufs['HC']
+        Y = self.buf('Y', Ms, 256)
+        self.dense_fwd(HC, 'concat_projection', Y, Ms, 512, 256)
+        prev = Y
+        for g in (1, 2):
+            sc = 'decoder_gru_%d' % g
+            XP = self.buf('xp%d' % g, Ms, 768)
+            self.gemm(prev, self.P(sc + '/wx'), self.P(sc + '/bias'), XP, Ms, 256, 768)
+            t = [self.buf('g%d_%s' % (g, k), Ms, 256) for k in ('r', 'u', 'c', 'rh', 'h')]
+            D = self.buf('D%d' % g, Ms, 256)
+            lib.taco_gru256_seq_fwd(XP, self.P(sc + '/whg'), self.P(sc + '/whc'), prev, t[0], t[1], t[2], t[3], t[4], D, z, N, S, st)
+            prev = D
+        MEL = self.buf('mel_out', N, To, nm)             # == decoder outputs [N,S,nm*r] (tacotron.py:97)
+        self.dense_fwd(prev, 'output_projection', MEL.view(Ms, nm * r), Ms, 256, nm * r)
+        POST = self.cbhg_fwd('post_cbhg', MEL.view(Mp, nm), N, To, nm, 8, (256, nm), None, training)
+        LIN = self.buf('lin_out', N, To, self.nf)
+        self.gemm(POST, self.P('linear/kernel'), self.P('linear/bias'), LIN, Mp, 256, self.nf, ldw=L.ld_lin, ldy=self.nf)
+        self.mel_outputs, self.linear_outputs = MEL, LIN
+        self.alignments = self._bufs['ALIGN'].view(N, S, Ti).transpose(1, 2)      # [N, Ti, S] (tacotron.py:104)
+        self.encoder_outputs = ENC.view(N, Ti, 256)
+        return MEL, LIN, self.alignments
+
+    def _make_attn_ptrs(self, N, S, Ti):
+        b = self.buf
+        W1 = self.P('decoder_prenet/dense_1/kernel')
+        t = {
+            'W1C': W1[self.nm:], 'F1': self._bufs['F1'], 'W2': self.P('decoder_prenet/dense_2/kernel'),
+            'B2': self.P('decoder_prenet/dense_2/bias'), 'WX': self.P('attention_gru/wx'), 'WHG': self.P('attention_gru/whg'),
+            'WHC': self.P('attention_gru/whc'), 'BG': self.P('attention_gru/bias'), 'WQ': self.P('attention/query_layer/kernel'),
+            'V': self.P('attention/attention_v'), 'KEYS': self._bufs['keys'], 'MEM': self._bufs['encoder_cbhg/out'],
+            'ZEROS': self._bufs['zeros'],
+            'P1': b('P1', N * S, 256), 'P2': b('P2', N * S, 128), 'R': b('aR', N * S, 256), 'U': b('aU', N * S, 256),
+            'C': b('aC', N * S, 256), 'RH': b('aRH', N * S, 256), 'HC': b('HC', N * S, 512), 'Q': b('Q', N * S, 256),
+            'ALIGN': b('ALIGN', N * S, Ti),
+            'DHC': b('dHC', N * S, 512), 'DXP': b('dXPa', N * S, 768), 'DP2': b('dP2', N * S, 128), 'DP1': b('dP1', N * S, 256),
+            'DQ': b('dQ', N * S, 256), 'DKEYS': b('dKEYS', N * Ti, 256), 'DMEM': b('dMEM', N * Ti, 256),
+            'DVPART': b('dVPART', N * ((Ti + 15) // 16), 256), 'DA': b('dA', N * Ti), 'DHT': b('dHT', N, 256),
+            'DHPART': b('dHPART', N, 256), 'DHCARRY': b('dHCARRY', N, 256), 'DCTX': b('dCTX', N, 256),
+            'DCTXCARRY': b('dCTXCARRY', N, 256),
+        }
+        arr = (ctypes.c_void_p * len(_AP))(*[t[n].data_ptr() for n in _AP])
+        self._attn_dims = (ctypes.c_int * 3)(N, S, Ti)
+        self._attn_keep = t
+        return arr
+
+    # ---- loss (models/tacotron.py:127-137) -----------------------------------------------------------------------------
+    def loss(self, linear_targets, with_grad=True):
+        N, Ti, To, S = self.dims
+        Mp, st = N * To, self.st
+        self.linear_targets = linear_targets
+        self.loss_sums = self.dslot(4)
+        dMEL = self.buf('dmel_loss', Mp, self.nm) if with_grad else None
+        dLIN = self.buf('dlin', Mp, self.L.ld_lin) if with_grad else None
+        lib.taco_l1_loss(self.mel_outputs, self.nm, self.mel_targets, self.nm, dMEL, self.nm, self.loss_sums, Mp, self.nm, 0,
+                         1.0 / (Mp * self.nm), 0.0, st)
+        lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin if with_grad else self.nf,
+                         self.loss_sums[2:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
+
+    def loss_values(self):
+        """(loss, mel_loss, linear_loss) as Python floats -- synchronises."""
+        N, Ti, To, S = self.dims
+        s = self.loss_sums.cpu().numpy()
+        mel = s[0] / (N * To * self.nm)
+        lin = 0.5 * s[2] / (N * To * self.nf) + 0.5 * s[3] / (N * To * self.npri)
+        return mel + lin, mel, lin
+
+    # ---- backward ---------------------------------------------------------------------------------------------------------
+    def backward(self):
+        L, st, b = self.L, self.st, self._bufs
+        N, Ti, To, S = self.dims
+        r, nm = self.r, self.nm
+        Me, Mp, Ms = N * Ti, N * To, N * S
+        E = L.Et + L.Es
+        self.grads.zero_()
+        dLIN, POST = b['dlin'], b['post_cbhg/out']
+        # linear layer (tacotron.py:101)
+        self.gemm_dw(POST, dLIN, self.G('linear/kernel'), Mp, 256, self.nf, ldw=L.ld_lin)
+        self.colsum(dLIN, self.G('linear/bias'), Mp, L.ld_lin)
+        dPOST = self.buf('dpost', Mp, 256)
+        self.gemm_dx(dLIN, self.P('linear/kernel'), dPOST, Mp, 256, L.ld_lin, ldw=L.ld_lin)
+        dMELp = self.buf('dmel_post', Mp, nm)
+        self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, dMELp)
+        dOUT = self.buf('dout', Ms, nm * r)
+        lib.taco_add(dMELp, b['dmel_loss'], dOUT, Mp * nm, 0, st)
+        # output projection
+        D2 = b['D2']
+        dD = self.buf('dD2', Ms, 256)
+        self.dense_bwd(D2, dOUT, 'output_projection', Ms, 256, nm * r, dx=dD)
+        z = b['zeros']
+        # residual GRUs, top to bottom
+        for g in (2, 1):
+            sc = 'decoder_gru_%d' % g
+            gin = b['D1'] if g == 2 else b['Y']
+            R, U, C, RH, Hh = (b['g%d_%s' % (g, k)] for k in ('r', 'u', 'c', 'rh', 'h'))
+            dXP = self.buf('dxp%d' % g, Ms, 768)
+            lib.taco_gru256_seq_bwd(dD, self.P(sc + '/whg'), self.P(sc + '/whc'), R, U, C, Hh, dXP,
+                                    self.buf('dhT', N, 256), self.buf('dhpart', N, 256), z, N, S, st)
+            self.gemm_dw(gin, dXP, self.G(sc + '/wx'), Ms, 256, 768)
+            self.colsum(dXP, self.G(sc + '/bias'), Ms, 768)
+            self.gemm_dw_shift(Hh, dXP, self.G(sc + '/whg'), Ms, S, 256, 512, 256, 768, 512)
+            self.gemm_dw(RH, dXP[:, 512:], self.G(sc + '/whc'), Ms, 256, 256, ldx=256, lddy=768, ldw=256)
+            self.gemm_dx(dXP, self.P(sc + '/wx'), dD, Ms, 256, 768, acc=1)     # dD_{g-1} = dD_g (residual) + dXP.Wx^T
+        dY = dD
+        dHC = b['dHC']
+        self.dense_bwd(b['HC'], dY, 'concat_projection', Ms, 512, 256, dx=dHC)
+        # attention recurrence
+        for k in ('dQ', 'dKEYS', 'dMEM', 'dVPART'):
+            b[k].zero_()
+        lib.taco_attn_rnn_bwd(self._attn_ptrs, self._attn_dims, st)
+        HC, dXPa, dP2, dP1, dQ = b['HC'], b['dXPa'], b['dP2'], b['dP1'], b['dQ']
+        self.gemm_dw(b['P2'], dXPa, self.G('attention_gru/wx'), Ms, 128, 768)
+        self.colsum(dXPa, self.G('attention_gru/bias'), Ms, 768)
+        self.gemm_dw_shift(HC, dXPa, self.G('attention_gru/whg'), Ms, S, 256, 512, 512, 768, 512)
+        self.gemm_dw(b['aRH'], dXPa[:, 512:], self.G('attention_gru/whc'), Ms, 256, 256, ldx=256, lddy=768, ldw=256)
+        self.gemm_dw(HC, dQ, self.G('attention/query_layer/kernel'), Ms, 256, 256, ldx=512)
+        nch = (Ti + 15) // 16
+        self.colsum(b['dVPART'], self.G('attention/attention_v'), N * nch, 256)
+        self.gemm_dw(b['P1'], dP2, self.G('decoder_prenet/dense_2/kernel'), Ms, 256, 128)
+        self.colsum(dP2, self.G('decoder_prenet/dense_2/bias'), Ms, 128)
+        dW1 = self.G('decoder_prenet/dense_1/kernel')
+        self.gemm_dw(b['frames'], dP1, dW1, Ms, nm, 256)
+        self.gemm_dw_shift(HC[:, 256:], dP1, dW1[nm:], Ms, S, 256, 256, 512, 256, 256)
+        self.colsum(dP1, self.G('decoder_prenet/dense_1/bias'), Ms, 256)
+        # encoder outputs: values (dMEM) + keys path
+        ENC, dKEYS, dENC = b['encoder_cbhg/out'], b['dKEYS'], b['dMEM']
+        self.gemm_dw(ENC, dKEYS, self.G('attention/memory_layer/kernel'), Me, 256, 256)
+        self.gemm_dx(dKEYS, self.P('attention/memory_layer/kernel'), dENC, Me, 256, 256, acc=1)
+        dA2 = self.buf('d_enc_p2', Me, 128)
+        self.cbhg_bwd('encoder_cbhg', b['enc_p2'], dENC, N, Ti, 128, 16, (128, 128), self.input_lengths, dA2)
+        # encoder prenet + embeddings
+        lib.taco_relu_bwd(b['enc_p2'], dA2, dA2, Me * 128, st)
+        dA1 = self.buf('d_enc_p1', Me, 256)
+        self.dense_bwd(b['enc_p1'], dA2, 'prenet/dense_2', Me, 256, 128, dx=dA1)
+        lib.taco_relu_bwd(b['enc_p1'], dA1, dA1, Me * 256, st)
+        dX0 = self.buf('d_emb', Me, E)
+        self.dense_bwd(b['emb'], dA1, 'prenet/dense_1', Me, E, 256, dx=dX0)
+        self.gnorm2 = self.dslot(2)
+        lib.taco_embed_scatter_bwd(self.inputs, self.identities if L.Es else None, dX0, self.G('embedding'),
+                                   self.G('embedding_id') if L.Es else None,
+                                   self.gnorm2 if (self.tf_sparse_norm and self.world == 1) else None,
+                                   N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
+
+    # ---- optimizer (models/tacotron.py:174-202) ---------------------------------------------------------------------------
+    def optimizer_step(self):
+        L, st = self.L, self.st
+        if self.tf_sparse_norm and self.world == 1:
+            # tf.global_norm: dense tensors + un-deduplicated IndexedSlices rows (already in gnorm2)
+            lib.taco_sumsq(self.grads[L.dense_start:], L.total - L.dense_start, self.gnorm2, st)
+        else:
+            lib.taco_sumsq(self.grads, L.total, self.gnorm2, st)
+        lib.taco_adam_step(self.params, self.grads, self.m, self.v, L.total, self.gnorm2, self.global_step, self.init_lr,
+                           1 if self.decay_lr else 0, self.beta1, self.beta2, 1e-8, 1.0, self.info, st)
+        if L.bn_total:
+            lib.taco_bn_ema(self.bn, self.bnbatch, L.bn_total, BN_MOMENTUM, st)     # UPDATE_OPS (tacotron.py:193)
+        lib.taco_step_inc(self.global_step, st)
+
+    def allreduce_grads(self):
+        """Data parallel exchange step (net-new): RCCL all-reduce(sum)/world of the flat gradient."""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads)
+            lib.taco_scale(self.grads, self.L.total, 1.0 / self.world, self.st)
+
+    def train_step(self, inputs, input_lengths, mel_targets, linear_targets, identities=None):
+        self.forward(inputs, input_lengths, mel_targets, identities, training=True)
+        self.loss(linear_targets)
+        self.backward()
+        self.allreduce_grads()
+        self.optimizer_step()
