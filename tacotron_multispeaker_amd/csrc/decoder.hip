@@ -19,11 +19,13 @@
 #include "common.hpp"
 
 // ---------------------------------------------------------------------------------------------------
-// skinny GEMM: out[M<=32 rows/tile, 16 cols/workgroup] = sum over up to 2 (A,B) segments, K split over 4 waves
+// skinny GEMM: out[M<=32 rows/tile, 16 cols/workgroup] = sum over up to 2 (A,B) segments, K split over 8 waves
 // ---------------------------------------------------------------------------------------------------
 enum {
     M_PRENET1 = 0, M_BIAS_RELU, M_LINEAR, M_GRU_GATES, M_GRU_CAND, M_GRU_BWD1, M_GRU_BWD2, M_RELU_MASK
 };
+
+#define SK_WAVES 8
 
 struct Skinny {
     const float* A0; int lda0; int K0; const float* B0; int ldb0;
@@ -39,6 +41,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// One wave's share of a segment: chunks of 16 k (4 per lane-quarter); loads of up to 4 chunks are issued
+// back-to-back before the first MFMA so a wave pays ~one L2 round trip per 64 k instead of one per 16 k.
 template <bool BT>
 __device__ __forceinline__ void skinny_acc(f32x4 (&acc)[2], const Skinny& p, const float* __restrict__ A, int lda, int K,
                                            const float* __restrict__ B, int ldb, int m0, int n0, int wave, int lane,
@@ -46,46 +50,56 @@ __device__ __forceinline__ void skinny_acc(f32x4 (&acc)[2], const Skinny& p, con
     const int i = lane & 15, kq = lane >> 4;
     const int col = n0 + i;
     const bool col_ok = col < p.N;
-    // this wave's K range (multiples of 16)
     const int chunks = (K + 15) / 16;
-    const int per = (chunks + 3) / 4;
+    const int per = (chunks + SK_WAVES - 1) / SK_WAVES;
     const int c0 = wave * per, c1 = min(chunks, c0 + per);
-    for (int ch = c0; ch < c1; ++ch) {
-        const int k = ch * 16 + 4 * kq;
-        const bool k_ok = k < K;
-        float a[2][4], b[4];
+    const int row0 = m0 + i, row1 = m0 + 16 + i;
+    const bool r0ok = row0 < p.M, r1ok = row1 < p.M;
+    for (int cb = c0; cb < c1; cb += 4) {
+        float4 a0[4], a1[4], b[4];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int row = m0 + rt * 16 + i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < p.M && k_ok) {
-                v = *reinterpret_cast<const float4*>(A + (long)row * lda + k);
-                if (amode1) {   // a = dhT * (1-u) * (1-c^2): candidate pre-activation gradient recomputed on load
-                    const float4 u = *reinterpret_cast<const float4*>(p.p[2] + (long)row * p.ld[2] + k);
-                    const float4 c = *reinterpret_cast<const float4*>(p.p[3] + (long)row * p.ld[3] + k);
-                    v.x *= (1.f - u.x) * (1.f - c.x * c.x); v.y *= (1.f - u.y) * (1.f - c.y * c.y);
-                    v.z *= (1.f - u.z) * (1.f - c.z * c.z); v.w *= (1.f - u.w) * (1.f - c.w * c.w);
+        for (int u = 0; u < 4; ++u) {
+            const int k = (cb + u) * 16 + 4 * kq;
+            const bool k_ok = (cb + u) < c1 && k < K;
+            a0[u] = make_float4(0.f, 0.f, 0.f, 0.f); a1[u] = a0[u]; b[u] = a0[u];
+            if (r0ok && k_ok) a0[u] = *reinterpret_cast<const float4*>(A + (long)row0 * lda + k);
+            if (r1ok && k_ok) a1[u] = *reinterpret_cast<const float4*>(A + (long)row1 * lda + k);
+            if (BT) {
+                if (col_ok && k_ok) b[u] = *reinterpret_cast<const float4*>(B + (long)col * ldb + k);
+            } else if (col_ok && k_ok) {
+                b[u].x = B[(long)(k + 0) * ldb + col]; b[u].y = B[(long)(k + 1) * ldb + col];
+                b[u].z = B[(long)(k + 2) * ldb + col]; b[u].w = B[(long)(k + 3) * ldb + col];
+            }
+            if (amode1) {   // a = dhT * (1-u) * (1-c^2): candidate pre-activation gradient recomputed on load
+                if (r0ok && k_ok) {
+                    const float4 uu = *reinterpret_cast<const float4*>(p.p[2] + (long)row0 * p.ld[2] + k);
+                    const float4 cc = *reinterpret_cast<const float4*>(p.p[3] + (long)row0 * p.ld[3] + k);
+                    a0[u].x *= (1.f - uu.x) * (1.f - cc.x * cc.x); a0[u].y *= (1.f - uu.y) * (1.f - cc.y * cc.y);
+                    a0[u].z *= (1.f - uu.z) * (1.f - cc.z * cc.z); a0[u].w *= (1.f - uu.w) * (1.f - cc.w * cc.w);
+                }
+                if (r1ok && k_ok) {
+                    const float4 uu = *reinterpret_cast<const float4*>(p.p[2] + (long)row1 * p.ld[2] + k);
+                    const float4 cc = *reinterpret_cast<const float4*>(p.p[3] + (long)row1 * p.ld[3] + k);
+                    a1[u].x *= (1.f - uu.x) * (1.f - cc.x * cc.x); a1[u].y *= (1.f - uu.y) * (1.f - cc.y * cc.y);
+                    a1[u].z *= (1.f - uu.z) * (1.f - cc.z * cc.z); a1[u].w *= (1.f - uu.w) * (1.f - cc.w * cc.w);
                 }
             }
-            a[rt][0] = v.x; a[rt][1] = v.y; a[rt][2] = v.z; a[rt][3] = v.w;
-        }
-        if (BT) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col_ok && k_ok) v = *reinterpret_cast<const float4*>(B + (long)col * ldb + k);
-            b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = (col_ok && k + q < K) ? B[(long)(k + q) * ldb + col] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], b[q], acc[rt], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].x, b[u].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].x, b[u].x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].y, b[u].y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].y, b[u].y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].z, b[u].z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].z, b[u].z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].w, b[u].w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u].w, b[u].w, acc[1], 0, 0, 0);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void skinny_k(Skinny p) {
+__global__ __launch_bounds__(SK_WAVES * 64) void skinny_k(Skinny p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32;
     f32x4 acc[2];
@@ -100,19 +114,21 @@ __global__ __launch_bounds__(256) void skinny_k(Skinny p) {
         if (p.A0) skinny_acc<false>(acc, p, p.A0, p.lda0, p.K0, p.B0, p.ldb0, m0, n0, wave, lane, false);
         if (p.A1) skinny_acc<false>(acc, p, p.A1, p.lda1, p.K1, p.B1, p.ldb1, m0, n0, wave, lane, false);
     }
-    __shared__ float red[4][2][256];
+    __shared__ float red[SK_WAVES][2][256];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][rt][lane * 4 + r] = acc[rt][r];
     __syncthreads();
+    {
+        const int rt = tid >> 8, e = tid & 255;       // 512 threads <-> 2 x 256 outputs
+        float v = 0.0f;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const float v = red[0][rt][tid] + red[1][rt][tid] + red[2][rt][tid] + red[3][rt][tid];
-        const int l = tid >> 2, r = tid & 3;
+        for (int w = 0; w < SK_WAVES; ++w) v += red[w][rt][e];
+        const int l = e >> 2, r = e & 3;
         const int row = m0 + rt * 16 + (l >> 4) * 4 + r;
         const int col = n0 + (l & 15);
-        if (row >= p.M || col >= p.N) continue;
+        if (row >= p.M || col >= p.N) return;
         const long R = row;
         switch (p.mode) {
             case M_PRENET1:
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256) void skinny_k(Skinny p) {
 }
 
 static inline void launch_skinny(const Skinny& p, hipStream_t st) {
-    hipLaunchKernelGGL(skinny_k, dim3(cdiv(p.N, 16), cdiv(p.M, 32)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(skinny_k, dim3(cdiv(p.N, 16), cdiv(p.M, 32)), dim3(SK_WAVES * 64), 0, st, p);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -423,11 +423,14 @@ class Engine:
         lib.taco_step_inc(self.global_step, st)
 
     def allreduce_grads(self):
-        """Data parallel exchange step (net-new): RCCL all-reduce(sum)/world of the flat gradient."""
+        """Data parallel exchange step (net-new): RCCL all-reduce(sum)/world of the flat gradient,
+        in contiguous backward-order buckets (tacotron_multispeaker_amd/dp.py)."""
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads)
-            lib.taco_scale(self.grads, self.L.total, 1.0 / self.world, self.st)
+            from . import dp
+            if getattr(self, '_buckets', None) is None:
+                self._buckets = dp.bucket_ranges(self.L, 4)
+            dp.allreduce_average(self.grads, self.world, self._buckets,
+                                 scale_fn=lambda flat, s: lib.taco_scale(flat, flat.numel(), s, self.st))
 
     def train_step(self, inputs, input_lengths, mel_targets, linear_targets, identities=None):
         self.forward(inputs, input_lengths, mel_targets, identities, training=True)

@@ -1,0 +1,219 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI library, against the
+float64 oracle and the committed golden fixtures.  Tolerance: 1e-3 relative on mel / linear outputs
+(BASELINE.json north_star); gradients and the post-step parameters are held to the same relative bar
+(observed ~1e-5).  'Relative' = max|a-b| / max|b| per tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+TOL = 1e-3
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def dev_batch(b, dev):
+    t = lambda k, dt: torch.tensor(b[k], device=dev, dtype=dt) if b.get(k) is not None else None
+    return (t('inputs', torch.int32), t('input_lengths', torch.int32), t('mel_targets', torch.float32),
+            t('linear_targets', torch.float32), t('identities', torch.int32))
+
+
+def run_engine_step(P, b, r, idn, apply=True):
+    from tacotron_multispeaker_amd.engine import Engine
+    eng = Engine(id_num=idn, r=r, named_params=P)
+    i, l, m, lin, ids = dev_batch(b, eng.dev)
+    eng.forward(i, l, m, ids)
+    eng.loss(lin)
+    eng.backward()
+    torch.cuda.synchronize()
+    out = dict(mel=eng.mel_outputs.cpu().numpy(), lin=eng.linear_outputs.cpu().numpy(), align=eng.alignments.cpu().numpy(),
+               loss=eng.loss_values(), grads=eng.export_named('grads'))
+    if apply:
+        eng.optimizer_step()
+        torch.cuda.synchronize()
+        out['params'] = eng.export_named('params')
+        out['info'] = eng.info.cpu().numpy()
+        out['step'] = int(eng.global_step.item())
+    return out
+
+
+@pytest.mark.parametrize('name', ['tiny', 'multi_r2'])
+def test_training_step_matches_golden(name):
+    from oracle import tacotron_np as onp
+    g = np.load(os.path.join(GOLD, 'step_%s.npz' % name))
+    N, Ti, To, r, idn, ps, bs = [int(x) for x in g['config']]
+    P = onp.init_params(seed=ps, r=r, id_num=idn)
+    b = onp.synth_batch(N, Ti, To, r, seed=bs, id_num=idn)
+    o = run_engine_step(P, b, r, idn)
+    assert rel(o['mel'], g['mel_outputs']) < TOL
+    assert rel(o['lin'], g['linear_outputs']) < TOL
+    assert rel(o['align'], g['alignments']) < TOL
+    assert abs(o['loss'][0] - g['loss'][0]) < 1e-5 * g['loss'][0]
+    assert abs(o['info'][0] - float(g['global_norm'])) < 1e-4 * float(g['global_norm'])
+    assert abs(o['info'][1] - float(g['learning_rate'])) < 1e-6 * float(g['learning_rate'])
+    gmax = max(g['grad_l2'])
+    for n, l2, s in zip(g['grad_names'], g['grad_l2'], g['grad_sum']):
+        mine = o['grads'][str(n)].astype(np.float64)
+        assert abs(np.sqrt((mine ** 2).sum()) - l2) < TOL * l2 + 1e-7 * gmax, n      # bias-before-BN grads are exactly 0
+    for n, s, a in zip(g['param_names'], g['param_sum_after'], g['param_abs_after']):
+        mine = o['params'][str(n)].astype(np.float64)
+        assert abs(mine.sum() - s) < 1e-5 * a + 1e-6, n
+    assert o['step'] == 1
+
+
+@pytest.mark.parametrize('cfg', [(4, 48, 120, 5, 0), (5, 17, 35, 5, 0), (1, 9, 12, 3, 0), (3, 33, 16, 1, 7), (2, 40, 64, 2, 3)])
+def test_training_step_matches_oracle(cfg):
+    """ragged / odd batch sizes, r in {1,2,3,5}, single- and multi-speaker, perturbed BN/bias parameters."""
+    from oracle import tacotron_np as onp, tacotron_torch as ot
+    N, Ti, To, r, idn = cfg
+    P = onp.init_params(seed=21, r=r, id_num=idn)
+    rng = np.random.RandomState(5)
+    for k in P:                                   # move biases / BN affine away from their trivial initial values
+        if k.endswith(('/bias', '/beta')):
+            P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+        if k.endswith('/gamma'):
+            P[k] = P[k] * (1 + 0.2 * rng.standard_normal(P[k].shape))
+    b = onp.synth_batch(N, Ti, To, r, seed=31, id_num=idn)
+    if N > 1:
+        b['input_lengths'][0] = 1                 # shortest possible text: EOS only
+        b['inputs'][0, :] = 0; b['inputs'][0, 0] = 1
+    ts = ot.TrainState(P, torch.float64, id_num=idn, r=r)
+    last = ts.forward_backward(b)
+    info = ts.apply(last)
+    o = run_engine_step(P, b, r, idn)
+    assert rel(o['mel'], last['out']['mel_outputs'].detach().numpy()) < TOL
+    assert rel(o['lin'], last['out']['linear_outputs'].detach().numpy()) < TOL
+    assert rel(o['align'], last['out']['alignments'].detach().numpy()) < TOL
+    assert abs(o['loss'][0] - last['loss']) < 1e-5 * last['loss']
+    assert abs(o['info'][0] - info['global_norm']) < 1e-4 * info['global_norm']
+    gmax = max(float(v.abs().max()) for v in last['grads'].values())
+    for k, v in last['grads'].items():
+        v = v.numpy()
+        assert np.abs(o['grads'][k] - v).max() < TOL * np.abs(v).max() + 1e-6 * gmax, k
+    for k, v in ts.P.items():
+        assert np.abs(o['params'][k] - v.detach().numpy()).max() < 2e-6, k
+
+
+def test_full_size_c2_forward_matches_cpu_restatement():
+    """BASELINE config 2 (N=32, T_in=128, T_out=640, r=5) forward + loss against the fp32 CPU restatement."""
+    from oracle import tacotron_np as onp, tacotron_torch as ot
+    from tacotron_multispeaker_amd.engine import Engine
+    N, Ti, To, r = 32, 128, 640, 5
+    P = onp.init_params(seed=0, r=r)
+    b = onp.synth_batch(N, Ti, To, r, seed=1234)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    Pt = ot.to_torch(P, torch.float32, requires_grad=False)
+    with torch.no_grad():
+        ref = ot.forward(Pt, b['inputs'], b['input_lengths'], torch.tensor(b['mel_targets']), None, 0, r)
+        ref_loss = float(ot.loss_fn(ref['mel_outputs'], ref['linear_outputs'], torch.tensor(b['mel_targets']),
+                                    torch.tensor(b['linear_targets']))[0])
+    eng = Engine(r=r, named_params=P)
+    i, l, m, lin, _ = dev_batch(b, eng.dev)
+    eng.forward(i, l, m)
+    eng.loss(lin)
+    torch.cuda.synchronize()
+    assert rel(eng.mel_outputs.cpu().numpy(), ref['mel_outputs'].numpy()) < TOL
+    assert rel(eng.linear_outputs.cpu().numpy(), ref['linear_outputs'].numpy()) < TOL
+    assert rel(eng.alignments.cpu().numpy(), ref['alignments'].numpy()) < TOL
+    assert abs(eng.loss_values()[0] - ref_loss) < 1e-4 * ref_loss
+    # size-independent properties: alignments are distributions over ALL T_in; padded encoder rows are zero
+    al = eng.alignments.cpu().numpy()
+    assert np.abs(al.sum(axis=1) - 1).max() < 1e-5 and al.min() >= 0
+    enc = eng.encoder_outputs.cpu().numpy()
+    for n in range(N):
+        assert np.all(enc[n, b['input_lengths'][n]:] == 0)
+
+
+def test_full_size_training_reduces_loss_and_replays_from_graph():
+    from tacotron_multispeaker_amd.engine import Engine
+    from tacotron_multispeaker_amd import synth
+    eng = Engine(r=5, seed=0, init_lr=0.002, decay_lr=False)
+    args = synth.batch_to_device(synth.synth_batch(32, 128, 640, 5, seed=1234), eng.dev)
+    eng.train_step(*args[:4])
+    first = eng.loss_values()[0]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.train_step(*args[:4])
+    for _ in range(8):
+        g.replay()
+    torch.cuda.synchronize()
+    last = eng.loss_values()[0]
+    assert np.isfinite(last) and last < first
+    assert int(eng.global_step.item()) == 10
+
+
+# ---- operator-level checks against torch (fp64 on the same device) ----------------------------------------
+def _conv_ref(x, w, b, T):
+    N = x.shape[0] // T
+    y = torch.nn.functional.conv1d(x.view(N, T, -1).transpose(1, 2), w.permute(2, 1, 0), b, padding='same')
+    return y.transpose(1, 2).reshape(x.shape[0], -1)
+
+
+@pytest.mark.parametrize('M,T,cin,cout,kw', [(96, 12, 128, 128, 3), (4096, 128, 256, 1024, 1), (330, 33, 80, 256, 3),
+                                             (2560, 640, 1024, 256, 3), (77, 77, 256, 1025, 1), (64, 16, 336, 256, 2)])
+def test_conv_gemm_forward_backward(M, T, cin, cout, kw):
+    from tacotron_multispeaker_amd._lib import lib, stream
+    torch.manual_seed(M + kw)
+    dev = 'cuda'
+    ldw = (cout + 3) & ~3
+    x = torch.randn(M, cin, device=dev)
+    w = torch.zeros(kw, cin, ldw, device=dev); w[:, :, :cout] = torch.randn(kw, cin, cout, device=dev) / np.sqrt(cin * kw)
+    b = torch.randn(ldw, device=dev)
+    y = torch.empty(M, cout, device=dev)
+    lib.taco_conv_gemm_fwd(x, w, b, y, M, T, cin, cout, kw, 0, cin, ldw, cout, 1, 0, stream())
+    x64 = x.double().requires_grad_(True)
+    w64 = w[:, :, :cout].double().requires_grad_(True)
+    ref = torch.relu(_conv_ref(x64, w64, b[:cout].double(), T))
+    assert rel(y.cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+    dy = torch.zeros(M, ldw, device=dev); dy[:, :cout] = torch.randn(M, cout, device=dev)
+    pre = _conv_ref(x64, w64, b[:cout].double(), T)
+    pre.backward(dy[:, :cout].double())
+    dx = torch.empty(M, cin, device=dev)
+    lib.taco_conv_gemm_bwd_data(dy, w, dx, M, T, cin, ldw, kw, 0, ldw, ldw, cin, 0, stream())
+    assert rel(dx.cpu().numpy(), x64.grad.cpu().numpy()) < 1e-5
+    dw = torch.zeros(kw, cin, ldw, device=dev)
+    lib.taco_conv_gemm_bwd_weight(x, dy, dw, M, T, cin, cout, kw, 0, cin, ldw, ldw, stream())
+    assert rel(dw[:, :, :cout].cpu().numpy(), w64.grad.cpu().numpy()) < 1e-5
+    assert float(dw[:, :, cout:].abs().max()) == 0 if ldw > cout else True
+
+
+@pytest.mark.parametrize('N,T,cin,K', [(3, 20, 128, 16), (2, 35, 80, 8), (32, 128, 128, 16)])
+def test_conv_bank(N, T, cin, K):
+    from tacotron_multispeaker_amd._lib import lib, stream
+    dev, M, C = 'cuda', N * T, K * 128
+    torch.manual_seed(K)
+    x = torch.randn(M, cin, device=dev)
+    ws = [torch.randn(k, cin, 128, device=dev) / np.sqrt(cin * k) for k in range(1, K + 1)]
+    wp = torch.cat(ws, 0).contiguous()
+    b = torch.randn(C, device=dev)
+    y = torch.empty(M, C, device=dev)
+    lib.taco_conv_gemm_fwd(x, wp, b, y, M, T, cin, C, K, K, cin, 128, C, 1, 0, stream())
+    x64 = x.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in ws]
+    pre = torch.cat([_conv_ref(x64, w, b[(k) * 128:(k + 1) * 128].double(), T) for k, w in enumerate(w64)], 1)
+    assert rel(y.cpu().numpy(), torch.relu(pre).detach().cpu().numpy()) < 1e-5
+    dy = torch.randn(M, C, device=dev)
+    pre.backward(dy.double())
+    dx = torch.empty(M, cin, device=dev)
+    lib.taco_conv_gemm_bwd_data(dy, wp, dx, M, T, cin, C, K, K, C, 128, cin, 0, stream())
+    assert rel(dx.cpu().numpy(), x64.grad.cpu().numpy()) < 1e-5
+    dw = torch.zeros_like(wp)
+    lib.taco_conv_gemm_bwd_weight(x, dy, dw, M, T, cin, C, K, K, cin, C, 128, stream())
+    assert rel(dw.cpu().numpy(), torch.cat([w.grad for w in w64], 0).cpu().numpy()) < 1e-5
+
+
+def test_empty_and_invalid_arguments_are_rejected():
+    from tacotron_multispeaker_amd._lib import lib, stream
+    x = torch.zeros(16, 8, device='cuda')
+    with pytest.raises(RuntimeError, match='-22'):
+        lib.taco_conv_gemm_fwd(x, x, None, x, 0, 1, 8, 8, 1, 0, 8, 8, 8, 0, 0, stream())      # M = 0
+    with pytest.raises(RuntimeError, match='-22'):
+        lib.taco_conv_gemm_fwd(x, x, None, x, 16, 16, 8, 8, 1, 0, 6, 8, 8, 0, 0, stream())     # ld not a multiple of 4
+    with pytest.raises(RuntimeError, match='-22'):
+        lib.taco_gru128_seq_fwd(None, 768, x, x, x, x, None, x, 256, x, 1, 1, 2, stream())     # null xp
