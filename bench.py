@@ -81,6 +81,7 @@ def cpu_baseline(N, Ti, To, r, steps=2):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)                 # the GPU box's CPU share per GPU; more threads only add contention
     torch.set_num_threads(cores)
     P = onp.init_params(seed=0, r=r)
     ts = ot.TrainState(P, torch.float32, r=r)

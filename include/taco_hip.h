@@ -91,12 +91,13 @@ int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int
 /* attention recurrence; ptrs = device pointer table indexed by enum TacoAttnPtr, dims = {N, S, Ti} (host arrays) */
 int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stream);
-/* residual decoder GRU(256) with hoisted input projection xp [N,S,768]; d = res + h when d != NULL */
+/* residual decoder GRU(256), whole recurrence in one persistent cluster launch (csrc/gru256.hip); hoisted input
+ * projection xp [N,S,768]; d = res + h when d != NULL.  xchg: >= ceil(N/2)*6*256 8-byte granule slots of scratch,
+ * err: device int set to 1 if a bounded spin ever times out (results are then invalid).  N <= 128. */
 int taco_gru256_seq_fwd(const float* xp, const float* whg, const float* whc, const float* res, float* r, float* u, float* c,
-                        float* rh, float* h, float* d, const float* zeros, int N, int S, hipStream_t stream);
+                        float* rh, float* h, float* d, void* xchg, int* err, int N, int S, hipStream_t stream);
 int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, const float* r, const float* u, const float* c,
-                        const float* h, float* dxp, float* dhT, float* dhpart, const float* zeros, int N, int S,
-                        hipStream_t stream);
+                        const float* h, float* dxp, void* xchg, int* err, int N, int S, hipStream_t stream);
 
 /* ---- optimizer: tf.clip_by_global_norm + tf.train.AdamOptimizer + Noam lr + BN UPDATE_OPS (tacotron.py:174-202) -- */
 int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream);

@@ -47,7 +47,7 @@ def run(N, Ti, To, r, idn, seed=3, wscale=1.0):
     info = ts.apply(last)
     eng.optimizer_step()
     torch.cuda.synchronize()
-    print('gnorm', eng.info[:3].cpu().numpy(), info)
+    eng.check_errors(); print('gnorm', eng.info[:3].cpu().numpy(), info)
     pn = eng.export_named('params')
     worst = []
     for k, v in ts.P.items():

@@ -409,61 +409,6 @@ extern "C" int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipSt
     TACO_RETURN_LAST();
 }
 
-// Generic GRU(256) recurrence with hoisted input projection xp [N,S,768] (+bias folded in):
-// h_s = GRU(xp_s, h_{s-1});  optional residual output d_s = res_s + h_s  (ResidualWrapper, tacotron.py:78-79)
-extern "C" int taco_gru256_seq_fwd(const float* xp, const float* whg, const float* whc, const float* res, float* r, float* u,
-                                   float* c, float* rh, float* h, float* d, const float* zeros, int N, int S, hipStream_t st) {
-    if (!xp || !whg || !whc || !r || !u || !c || !rh || !h || !zeros || N <= 0 || S <= 0) return TACO_EINVAL;
-    for (int s = 0; s < S; ++s) {
-        const bool first = s == 0;
-        const long o = (long)s * 256;
-        const float* hprev = first ? zeros : h + o - 256;
-        const int ldprev = first ? 256 : S * 256;
-        Skinny k{};
-        k.A0 = hprev; k.lda0 = ldprev; k.K0 = 256; k.B0 = whg; k.ldb0 = 512;
-        k.M = N; k.N = 512; k.mode = M_GRU_GATES; k.Hd = 256; k.p[0] = xp + (long)s * 768; k.ld[0] = S * 768;
-        k.p[2] = hprev; k.ld[2] = ldprev;
-        k.o[0] = r + o; k.ldo[0] = S * 256; k.o[1] = u + o; k.ldo[1] = S * 256; k.o[2] = rh + o; k.ldo[2] = S * 256;
-        launch_skinny(k, st);
-        k = Skinny{}; k.A0 = rh + o; k.lda0 = S * 256; k.K0 = 256; k.B0 = whc; k.ldb0 = 256;
-        k.M = N; k.N = 256; k.mode = M_GRU_CAND; k.Hd = 256; k.p[0] = xp + (long)s * 768 + 512; k.ld[0] = S * 768;
-        k.p[2] = hprev; k.ld[2] = ldprev; k.p[3] = u + o; k.ld[3] = S * 256;
-        k.o[0] = c + o; k.ldo[0] = S * 256; k.o[1] = h + o; k.ldo[1] = S * 256;
-        if (d) { k.o[2] = d + o; k.ldo[2] = S * 256; k.p[4] = res + o; k.ld[4] = S * 256; }
-        launch_skinny(k, st);
-    }
-    TACO_RETURN_LAST();
-}
-
-// BPTT of taco_gru256_seq_fwd.  dout [N,S,256] = gradient wrt h_s (for the residual wrapper: gradient wrt d_s);
-// produces dxp [N,S,768].  Scratch: dhT [N,256], dhpart [N,256].
-extern "C" int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, const float* r, const float* u,
-                                   const float* c, const float* h, float* dxp, float* dhT, float* dhpart, const float* zeros,
-                                   int N, int S, hipStream_t st) {
-    if (!dout || !whg || !whc || !r || !u || !c || !h || !dxp || !dhT || !dhpart || !zeros || N <= 0 || S <= 0) return TACO_EINVAL;
-    // dhT <- dout[S-1]
-    hipMemcpy2DAsync(dhT, 256 * sizeof(float), dout + (long)(S - 1) * 256, (size_t)S * 256 * sizeof(float), 256 * sizeof(float), N,
-                     hipMemcpyDeviceToDevice, st);
-    for (int s = S - 1; s >= 0; --s) {
-        const long o = (long)s * 256;
-        const float* hprev = s == 0 ? zeros : h + o - 256;
-        const int ldprev = s == 0 ? 256 : S * 256;
-        Skinny k{};
-        k.A0 = dhT; k.lda0 = 256; k.K0 = 256; k.B0 = whc; k.ldb0 = 256; k.bt = 1; k.amode = 1;
-        k.M = N; k.N = 256; k.mode = M_GRU_BWD1; k.Hd = 256;
-        k.p[0] = dhT; k.ld[0] = 256; k.p[1] = r + o; k.ld[1] = S * 256; k.p[2] = u + o; k.ld[2] = S * 256;
-        k.p[3] = c + o; k.ld[3] = S * 256; k.p[4] = hprev; k.ld[4] = ldprev;
-        k.o[0] = dxp + (long)s * 768; k.ldo[0] = S * 768; k.o[1] = dhpart; k.ldo[1] = 256;
-        launch_skinny(k, st);
-        k = Skinny{}; k.A0 = dxp + (long)s * 768; k.lda0 = S * 768; k.K0 = 512; k.B0 = whg; k.ldb0 = 512; k.bt = 1;
-        k.M = N; k.N = 256; k.mode = M_GRU_BWD2; k.p[0] = dhpart; k.ld[0] = 256;
-        if (s > 0) { k.p[1] = dout + o - 256; k.ld[1] = S * 256; }
-        k.o[0] = dhT; k.ldo[0] = 256;
-        launch_skinny(k, st);
-    }
-    TACO_RETURN_LAST();
-}
-
 // BPTT of the attention recurrence.  dHC [N,S,512] holds the external gradients wrt (h_s, ctx_s) from the
 // concat projection.  Produces dXP (attention GRU pre-activations) [N,S,768], dP2/dP1 (prenet pre-activations),
 // dQ [N,S,256] (pre-zeroed), dKEYS / dMEM [N,Ti,256] (pre-zeroed accumulators), dVPART [N,ceil(Ti/16),256] (pre-zeroed).

@@ -51,6 +51,7 @@ class Engine:
         self.global_step = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.dscratch = torch.zeros(1 << 16, dtype=torch.float64, device=self.dev)   # zeroed once per step
         self.info = torch.zeros(4, **f)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._bufs = {}
         self._dpos = 0
         self.world = 1
@@ -90,6 +91,15 @@ class Engine:
         s = self.dscratch[self._dpos:self._dpos + n]
         self._dpos += n
         return s
+
+    def xchg(self, N):
+        """granule scratch of the persistent cluster kernels (8-byte {epoch, value} slots)."""
+        return self.buf('xchg', ((N + 1) // 2) * 16 * 256, dtype=torch.int64)
+
+    def check_errors(self):
+        """raises if a bounded spin of a persistent kernel timed out (synchronises)."""
+        if int(self.err.item()) != 0:
+            raise RuntimeError('persistent cluster kernel reported a hand-off timeout; results are invalid')
 
     @property
     def st(self):
@@ -276,7 +286,8 @@ class Engine:
             self.gemm(prev, self.P(sc + '/wx'), self.P(sc + '/bias'), XP, Ms, 256, 768)
             t = [self.buf('g%d_%s' % (g, k), Ms, 256) for k in ('r', 'u', 'c', 'rh', 'h')]
             D = self.buf('D%d' % g, Ms, 256)
-            lib.taco_gru256_seq_fwd(XP, self.P(sc + '/whg'), self.P(sc + '/whc'), prev, t[0], t[1], t[2], t[3], t[4], D, z, N, S, st)
+            lib.taco_gru256_seq_fwd(XP, self.P(sc + '/whg'), self.P(sc + '/whc'), prev, t[0], t[1], t[2], t[3], t[4], D,
+                                    self.xchg(N), self.err, N, S, st)
             prev = D
         MEL = self.buf('mel_out', N, To, nm)             # == decoder outputs [N,S,nm*r] (tacotron.py:97)
         self.dense_fwd(prev, 'output_projection', MEL.view(Ms, nm * r), Ms, 256, nm * r)
@@ -362,7 +373,7 @@ class Engine:
             R, U, C, RH, Hh = (b['g%d_%s' % (g, k)] for k in ('r', 'u', 'c', 'rh', 'h'))
             dXP = self.buf('dxp%d' % g, Ms, 768)
             lib.taco_gru256_seq_bwd(dD, self.P(sc + '/whg'), self.P(sc + '/whc'), R, U, C, Hh, dXP,
-                                    self.buf('dhT', N, 256), self.buf('dhpart', N, 256), z, N, S, st)
+                                    self.xchg(N), self.err, N, S, st)
             self.gemm_dw(gin, dXP, self.G(sc + '/wx'), Ms, 256, 768)
             self.colsum(dXP, self.G(sc + '/bias'), Ms, 768)
             self.gemm_dw_shift(Hh, dXP, self.G(sc + '/whg'), Ms, S, 256, 512, 256, 768, 512)
