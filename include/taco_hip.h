@@ -91,6 +91,10 @@ int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int
 /* attention recurrence; ptrs = device pointer table indexed by enum TacoAttnPtr, dims = {N, S, Ti} (host arrays) */
 int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stream);
+/* persistent-cluster path of the attention recurrence: shape support (1/0) and granule scratch size in 8-byte slots */
+int taco_attn_cluster_supported(int N, int Ti);
+int taco_attn_cluster_xchg_slots(int N, int Ti);
+int taco_attn_cluster_bwd_xchg_slots(int N, int Ti);
 /* residual decoder GRU(256), whole recurrence in one persistent cluster launch (csrc/gru256.hip); hoisted input
  * projection xp [N,S,768]; d = res + h when d != NULL.  xchg: >= ceil(N/2)*6*256 8-byte granule slots of scratch,
  * err: device int set to 1 if a bounded spin ever times out (results are then invalid).  N <= 128. */
@@ -132,9 +136,13 @@ enum TacoAttnPtr {
     TACO_AP_DP2, TACO_AP_DP1, /* out: prenet pre-activation gradients         [N,S,128],[N,S,256] */
     TACO_AP_DQ,        /* out (pre-zeroed): query gradients                         [N,S,256] */
     TACO_AP_DKEYS, TACO_AP_DMEM, /* out (pre-zeroed accumulators)                   [N,Ti,256] each */
-    TACO_AP_DVPART,    /* out (pre-zeroed): attention_v partial gradients  [N,ceil(Ti/16),256] */
+    TACO_AP_DVPART,    /* out: attention_v partial gradients; per-step path [N,ceil(Ti/16),256] pre-zeroed, cluster path [N*Ti,256] */
     TACO_AP_DA,        /* scratch [N,Ti] */
     TACO_AP_DHT, TACO_AP_DHPART, TACO_AP_DHCARRY, TACO_AP_DCTX, TACO_AP_DCTXCARRY, /* scratch [N,256] each */
+    TACO_AP_XCHG,      /* optional: >= taco_attn_cluster_xchg_slots(N,Ti) 8-byte granule slots (enables the cluster path) */
+    TACO_AP_ERR,       /* optional: device int, set to 1 if a bounded hand-off spin timed out */
+    TACO_AP_DE,        /* cluster bwd: out, softmax-input gradients de_s[t]           [N,S,Ti] */
+    TACO_AP_DCTXS,     /* cluster bwd: out, total context gradients per step          [N,S,256] */
     TACO_AP_COUNT
 };
 

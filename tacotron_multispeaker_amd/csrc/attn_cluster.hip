@@ -1,0 +1,700 @@
+// Persistent CLUSTER kernel for the attention recurrence of the Tacotron decoder (teacher forcing), forward.
+//
+// Reference: AttentionWrapper(DecoderPrenetWrapper(GRUCell(256)), BahdanauAttention(256, encoder_outputs))
+// (models/tacotron.py:66-70, models/rnn_wrappers.py:22-24), semantics SURVEY Appendix A.5/A.7/A.8.
+//
+// One launch runs all S decoder steps.  A cluster of 8 workgroups (512 threads each) owns two batch rows; the
+// FEATURE axis is split 8 ways: workgroup w keeps, for the whole kernel,
+//   * in registers (112 VGPRs/lane): its column slices of the prenet (W1[80:336], W2), attention-GRU (Wx, Whg, Whc)
+//     and query (Wq) kernels -- 32 (16 for W2, 64 for the gates) output columns each, K split over lanes;
+//   * in LDS: the 32-column slices keys[row][:, D_w] and memory[row][:, D_w] of its two rows (Ti x 32 x 2 x 2 floats),
+//     i.e. the attention score tile never leaves the CU after the prologue.
+// Per step the cluster exchanges six vectors (ctx, p1, p2, r*h, h', partial scores) as 8-byte {epoch,value}
+// granules (one agent-scope store each, polled with agent-scope loads: Guideline 16 form R2).  Scores are reduced over
+// the 256-axis with cross-lane adds inside a workgroup and over workgroups by every member in the SAME order, so all
+// members compute bit-identical softmax weights (softmax over ALL Ti positions, no memory mask: Appendix A.7).
+// Clusters never talk to each other; grid = 8 * ceil(N/2) <= 256 co-resident workgroups; spins are bounded.
+#include "attn_cluster.hpp"
+
+#define CW 8                 // workgroups per cluster
+#define AT 512               // threads per workgroup
+#define SPIN_LIMIT (1 << 22)
+#define PIDX(k) ((k) + ((k) >> 4) * 4)          // LDS vector layout: 4 pad floats after every 16 (bank spreading)
+#define PLEN(n) ((n) + ((n) >> 4) * 4)
+
+__device__ __forceinline__ void put_g(u64* p, unsigned epoch, float v) {
+    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NG>
+__device__ __forceinline__ void get_g(const u64* const (&ptr)[NG], unsigned epoch, float (&out)[NG], int* err) {
+    u64 x[NG];
+    int spins = 0;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) x[i] = __hip_atomic_load(ptr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) all = all && ((unsigned)(x[i] >> 32) == epoch);
+        if (all) break;
+        if (++spins > SPIN_LIMIT) { atomicExch(err, 1); break; }
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) out[i] = __uint_as_float((unsigned)x[i]);
+}
+
+__device__ __forceinline__ float fast_tanh_(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// dot of this lane's K-part with the register weights, both rows; vec rows are PIDX-laid-out LDS vectors
+template <int KPER>
+__device__ __forceinline__ void dot2(const float* __restrict__ v0, const float* __restrict__ v1, int kbase,
+                                     const float (&w)[KPER], float& a0, float& a1) {
+#pragma unroll
+    for (int k4 = 0; k4 < KPER / 4; ++k4) {
+        const int k = kbase + k4 * 4;
+        const float4 x0 = *reinterpret_cast<const float4*>(v0 + PIDX(k));
+        const float4 x1 = *reinterpret_cast<const float4*>(v1 + PIDX(k));
+        a0 = fmaf(x0.x, w[k4 * 4], a0); a1 = fmaf(x1.x, w[k4 * 4], a1);
+        a0 = fmaf(x0.y, w[k4 * 4 + 1], a0); a1 = fmaf(x1.y, w[k4 * 4 + 1], a1);
+        a0 = fmaf(x0.z, w[k4 * 4 + 2], a0); a1 = fmaf(x1.z, w[k4 * 4 + 2], a1);
+        a0 = fmaf(x0.w, w[k4 * 4 + 3], a0); a1 = fmaf(x1.w, w[k4 * 4 + 3], a1);
+    }
+}
+template <int PARTS>
+__device__ __forceinline__ float lane_reduce(float v) {
+#pragma unroll
+    for (int o = 1; o < PARTS; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// gather the 7 peers' slices (LEN values per row per workgroup) of a published vector into a PIDX LDS vector [2][..]
+template <int LEN>
+__device__ __forceinline__ void gather_vec(const u64* region, float* lds0, float* lds1, int w, unsigned epoch, int tid, int* err) {
+    constexpr int TOT = 2 * (CW - 1) * LEN;
+    if (tid < TOT) {
+        const int row = tid / ((CW - 1) * LEN), rem = tid - row * (CW - 1) * LEN;
+        const int peer = rem / LEN, jj = rem - peer * LEN;
+        const int pw = peer + (peer >= w ? 1 : 0);
+        const int j = pw * LEN + jj;
+        const u64* const ptr[1] = {region + row * (CW * LEN) + j};
+        float val[1];
+        get_g<1>(ptr, epoch, val, err);
+        (row ? lds1 : lds0)[PIDX(j)] = val[0];
+    }
+}
+
+__global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int nclus = gridDim.x / CW;
+    int w, cl;
+    if ((nclus & 7) == 0) { const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3; w = qq & 7; cl = (qq >> 3) * 8 + xcd; }
+    else { w = blockIdx.x & 7; cl = blockIdx.x >> 3; }
+    const int Ti = p.Ti, S = p.S;
+    const int row0 = cl * 2;
+    const bool ok[2] = {row0 < p.N, row0 + 1 < p.N};
+    const long rw[2] = {(long)min(row0, p.N - 1), (long)min(row0 + 1, p.N - 1)};
+
+    // ---- LDS carve-up
+    float* ctx_l = smem;                          // [2][PLEN(256)]
+    float* p1_l = ctx_l + 2 * PLEN(256);
+    float* p2_l = p1_l + 2 * PLEN(256);           // [2][PLEN(128)]
+    float* h_l = p2_l + 2 * PLEN(128);
+    float* rh_l = h_l + 2 * PLEN(256);
+    float* u_l = rh_l + 2 * PLEN(256);            // [2][32]
+    float* q_l = u_l + 64;                        // [2][32]
+    float* ep_l = q_l + 64;                       // [2*Ti] own partial scores
+    float* a_l = ep_l + ((2 * Ti + 3) & ~3);      // [2*Ti] scores -> alignments
+    float* cp_l = a_l + ((2 * Ti + 3) & ~3);      // [8][64] context partials
+    float* red_l = cp_l + 512;                    // [8] softmax scratch
+    float* K_l = red_l + 16;                      // [2][Ti][32]
+    float* M_l = K_l + 2 * Ti * 32;               // [2][Ti][32]
+    for (int i = tid; i < 2 * PLEN(256) * 4 + 2 * PLEN(128); i += AT) smem[i] = 0.0f;    // ctx,p1,p2,h,rh = 0
+    for (int i = tid; i < 2 * Ti * 8; i += AT) {          // float4 granularity: (row, t, c4)
+        const int c4 = i & 7, t = (i >> 3) % Ti, row = (i >> 3) / Ti;
+        const long g = ((rw[row] * Ti) + t) * 256 + 32 * w + c4 * 4;
+        *reinterpret_cast<float4*>(K_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.keys + g);
+        *reinterpret_cast<float4*>(M_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.mem + g);
+    }
+
+    // ---- register-resident weight slices
+    const int cA = tid >> 4, pA = tid & 15;     // 32 cols x 16 parts (prenet1, cand, query)
+    const int cB = tid >> 5, pB = tid & 31;     // 16 cols x 32 parts (prenet2)
+    const int cC = tid >> 3, pC = tid & 7;      // 64 cols x  8 parts (gates)
+    const int gc = cC < 32 ? 32 * w + cC : 256 + 32 * w + (cC - 32);     // gate column: r_J | u_J
+    float w1[16], w2[8], wgx[16], wgh[32], wcx[8], wch[16], wqr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w1[k] = p.w1c[(long)(pA * 16 + k) * 256 + 32 * w + cA];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w2[k] = p.w2[(long)(pB * 8 + k) * 128 + 16 * w + cB];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wgx[k] = p.wx[(long)(pC * 16 + k) * 768 + gc];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wgh[k] = p.whg[(long)(pC * 32 + k) * 512 + gc];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wcx[k] = p.wx[(long)(pA * 8 + k) * 768 + 512 + 32 * w + cA];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wch[k] = p.whc[(long)(pA * 16 + k) * 256 + 32 * w + cA];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wqr[k] = p.wq[(long)(pA * 16 + k) * 256 + 32 * w + cA];
+    const float b2v = p.b2[16 * w + cB], bgv = p.bg[gc], bcv = p.bg[512 + 32 * w + cA];
+    // attention_v for this lane's 16 score dims (scores mapping: pair = tid>>1, half = tid&1)
+    float vv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vv[k] = p.v[32 * w + (tid & 1) * 16 + k];
+
+    // exchange regions of this cluster: CTX, P1 [2][256]; P2 [2][128]; RH, H [2][256]; E [8][2*Ti]
+    const long per_clu = 2 * 256 * 4 + 2 * 128 + (long)CW * 2 * Ti;
+    u64* X = p.xchg + (long)cl * per_clu;
+    u64 *xCTX = X, *xP1 = X + 512, *xP2 = X + 1024, *xRH = X + 1280, *xH = X + 1792, *xE = X + 2304;
+    __syncthreads();
+
+    for (int s = 0; s < S; ++s) {
+        const unsigned epoch = (unsigned)s + 1;
+        const long so0 = rw[0] * S + s, so1 = rw[1] * S + s;       // row offsets into [N,S,*] tensors
+        // ================= A: prenet dense_1 (context part; frame part + bias hoisted into f1) =================
+        {
+            const int j = 32 * w + cA;
+            float f0 = 0.f, f1v = 0.f;
+            if (pA == 0) { f0 = p.f1[so0 * 256 + j]; f1v = p.f1[so1 * 256 + j]; }
+            float a0 = 0.f, a1 = 0.f;
+            dot2<16>(ctx_l, ctx_l + PLEN(256), pA * 16, w1, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) {
+                a0 = fmaxf(a0 + f0, 0.f); a1 = fmaxf(a1 + f1v, 0.f);
+                p1_l[PIDX(j)] = a0; p1_l[PLEN(256) + PIDX(j)] = a1;
+                put_g(xP1 + j, epoch, a0); put_g(xP1 + 256 + j, epoch, a1);
+                if (ok[0]) p.p1[so0 * 256 + j] = a0;
+                if (ok[1]) p.p1[so1 * 256 + j] = a1;
+            }
+            gather_vec<32>(xP1, p1_l, p1_l + PLEN(256), w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= B: prenet dense_2 =================
+        {
+            const int j = 16 * w + cB;
+            float a0 = 0.f, a1 = 0.f;
+            dot2<8>(p1_l, p1_l + PLEN(256), pB * 8, w2, a0, a1);
+            a0 = lane_reduce<32>(a0); a1 = lane_reduce<32>(a1);
+            if (pB == 0) {
+                a0 = fmaxf(a0 + b2v, 0.f); a1 = fmaxf(a1 + b2v, 0.f);
+                p2_l[PIDX(j)] = a0; p2_l[PLEN(128) + PIDX(j)] = a1;
+                put_g(xP2 + j, epoch, a0); put_g(xP2 + 128 + j, epoch, a1);
+                if (ok[0]) p.p2[so0 * 128 + j] = a0;
+                if (ok[1]) p.p2[so1 * 128 + j] = a1;
+            }
+            gather_vec<16>(xP2, p2_l, p2_l + PLEN(128), w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= C: GRU gates =================
+        {
+            const int j = 32 * w + (cC & 31);
+            float a0 = 0.f, a1 = 0.f;
+            dot2<16>(p2_l, p2_l + PLEN(128), pC * 16, wgx, a0, a1);
+            dot2<32>(h_l, h_l + PLEN(256), pC * 32, wgh, a0, a1);
+            a0 = lane_reduce<8>(a0); a1 = lane_reduce<8>(a1);
+            if (pC == 0) {
+                const float g0 = sigmoidf_(a0 + bgv), g1 = sigmoidf_(a1 + bgv);
+                if (cC < 32) {
+                    const float q0 = g0 * h_l[PIDX(j)], q1 = g1 * h_l[PLEN(256) + PIDX(j)];
+                    rh_l[PIDX(j)] = q0; rh_l[PLEN(256) + PIDX(j)] = q1;
+                    put_g(xRH + j, epoch, q0); put_g(xRH + 256 + j, epoch, q1);
+                    if (ok[0]) { p.r[so0 * 256 + j] = g0; p.rh[so0 * 256 + j] = q0; }
+                    if (ok[1]) { p.r[so1 * 256 + j] = g1; p.rh[so1 * 256 + j] = q1; }
+                } else {
+                    u_l[cC - 32] = g0; u_l[32 + cC - 32] = g1;
+                    if (ok[0]) p.u[so0 * 256 + j] = g0;
+                    if (ok[1]) p.u[so1 * 256 + j] = g1;
+                }
+            }
+            gather_vec<32>(xRH, rh_l, rh_l + PLEN(256), w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= D: candidate + new state =================
+        {
+            const int j = 32 * w + cA;
+            float a0 = 0.f, a1 = 0.f;
+            dot2<8>(p2_l, p2_l + PLEN(128), pA * 8, wcx, a0, a1);
+            dot2<16>(rh_l, rh_l + PLEN(256), pA * 16, wch, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) {
+                const float c0 = tanhf_(a0 + bcv), c1 = tanhf_(a1 + bcv);
+                const float u0 = u_l[cA], u1 = u_l[32 + cA];
+                const float hn0 = u0 * h_l[PIDX(j)] + (1.f - u0) * c0;
+                const float hn1 = u1 * h_l[PLEN(256) + PIDX(j)] + (1.f - u1) * c1;
+                h_l[PIDX(j)] = hn0; h_l[PLEN(256) + PIDX(j)] = hn1;
+                put_g(xH + j, epoch, hn0); put_g(xH + 256 + j, epoch, hn1);
+                if (ok[0]) { p.c[so0 * 256 + j] = c0; p.hc[so0 * 512 + j] = hn0; }
+                if (ok[1]) { p.c[so1 * 256 + j] = c1; p.hc[so1 * 512 + j] = hn1; }
+            }
+            gather_vec<32>(xH, h_l, h_l + PLEN(256), w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= E: query slice =================
+        {
+            float a0 = 0.f, a1 = 0.f;
+            dot2<16>(h_l, h_l + PLEN(256), pA * 16, wqr, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) {
+                q_l[cA] = a0; q_l[32 + cA] = a1;
+                if (ok[0]) p.q[so0 * 256 + 32 * w + cA] = a0;
+                if (ok[1]) p.q[so1 * 256 + 32 * w + cA] = a1;
+            }
+        }
+        __syncthreads();
+        // ================= F: partial scores over this workgroup's 32 dims, all t =================
+        for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
+            const int half = tid & 1;
+            const int row = i >= Ti;
+            const float* kp = K_l + i * 32 + half * 16;
+            const float* qp = q_l + row * 32 + half * 16;
+            float e = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const float4 kv = *reinterpret_cast<const float4*>(kp + d4 * 4);
+                const float4 qv = *reinterpret_cast<const float4*>(qp + d4 * 4);
+                e = fmaf(vv[d4 * 4], fast_tanh_(kv.x + qv.x), e); e = fmaf(vv[d4 * 4 + 1], fast_tanh_(kv.y + qv.y), e);
+                e = fmaf(vv[d4 * 4 + 2], fast_tanh_(kv.z + qv.z), e); e = fmaf(vv[d4 * 4 + 3], fast_tanh_(kv.w + qv.w), e);
+            }
+            e += __shfl_xor(e, 1, 64);
+            if (half == 0) { ep_l[i] = e; put_g(xE + (long)w * 2 * Ti + i, epoch, e); }
+        }
+        __syncthreads();
+        // gather + reduce the 8 partials of every (row,t) in workgroup order (bit-identical in all members)
+        for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
+            const int half = tid & 1;
+            float val[4];
+            const u64* ptr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pw = half * 4 + k;
+                ptr[k] = xE + (long)(pw == w ? ((w + 1) & 7) : pw) * 2 * Ti + i;       // own slot replaced by a dummy peer
+            }
+            const u64* const cptr[4] = {ptr[0], ptr[1], ptr[2], ptr[3]};
+            get_g<4>(cptr, epoch, val, p.err);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? ep_l[i] : val[k];
+            const float other = __shfl_xor(sum, 1, 64);
+            if (half == 0) a_l[i] = sum + other;
+        }
+        __syncthreads();
+        // ================= G: softmax over all Ti (wave 0 -> row 0, wave 1 -> row 1) =================
+        if (tid < 128) {
+            const int row = tid >> 6, lane = tid & 63;
+            float* ar = a_l + row * Ti;
+            float mx = -INFINITY;
+            for (int t = lane; t < Ti; t += 64) mx = fmaxf(mx, ar[t]);
+            mx = wave_max(mx);
+            float sm = 0.f;
+            for (int t = lane; t < Ti; t += 64) { const float x = expf(ar[t] - mx); ar[t] = x; sm += x; }
+            sm = wave_sum(sm);
+            const float inv = 1.0f / sm;
+            for (int t = lane; t < Ti; t += 64) ar[t] *= inv;
+        }
+        __syncthreads();
+        // alignments to HBM: member w writes t = w, w+8, ...
+        for (int i = tid; i < 2 * Ti; i += AT) {
+            const int row = i >= Ti, t = i - row * Ti;
+            if ((t & 7) == w && ok[row]) p.align[(rw[row] * S + s) * Ti + t] = a_l[i];
+        }
+        // ================= H: context slice: ctx[row][d] = sum_t a[t] * mem[t][d] =================
+        {
+            const int row = tid >> 8, tp = (tid >> 5) & 7, d = tid & 31;
+            const float* ar = a_l + row * Ti;
+            const float* mr = M_l + row * Ti * 32 + d;
+            float acc = 0.f;
+            for (int t = tp; t < Ti; t += 8) acc = fmaf(ar[t], mr[t * 32], acc);
+            cp_l[tp * 64 + row * 32 + d] = acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int row = tid >> 5, d = tid & 31, j = 32 * w + d;
+            float cx = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 8; ++tp) cx += cp_l[tp * 64 + tid];
+            ctx_l[row * PLEN(256) + PIDX(j)] = cx;
+            put_g(xCTX + row * 256 + j, epoch, cx);
+            if (ok[row]) p.hc[(rw[row] * S + s) * 512 + 256 + j] = cx;
+        }
+        gather_vec<32>(xCTX, ctx_l, ctx_l + PLEN(256), w, epoch, tid, p.err);
+        __syncthreads();
+    }
+}
+
+extern "C" int taco_attn_cluster_xchg_slots(int N, int Ti) {
+    return ((N + 1) / 2) * (2 * 256 * 4 + 2 * 128 + CW * 2 * Ti);
+}
+
+static size_t attn_cluster_smem(int Ti) {
+    size_t f = 2 * PLEN(256) * 4 + 2 * PLEN(128) + 64 + 64 + 2 * ((2 * Ti + 3) & ~3) + 512 + 16 + (size_t)4 * Ti * 32;
+    return f * sizeof(float);
+}
+
+// returns 1 when the cluster path can run this shape
+static size_t attn_cluster_bwd_smem(int Ti);
+extern "C" int taco_attn_cluster_supported(int N, int Ti) {
+    return (CW * ((N + 1) / 2) <= 256 && attn_cluster_smem(Ti) <= 160 * 1024 && attn_cluster_bwd_smem(Ti) <= 160 * 1024 &&
+            Ti >= 1) ? 1 : 0;
+}
+
+int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
+    const size_t smem = attn_cluster_smem(p.Ti);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attn_cluster_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return TACO_EINVAL;
+        attr_set = true;
+    }
+    if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    hipLaunchKernelGGL(attn_cluster_fwd_k, dim3(CW * ((p.N + 1) / 2)), dim3(AT), smem, st, p);
+    TACO_RETURN_LAST();
+}
+
+// =====================================================================================================================
+// Backward (BPTT) of the attention recurrence as a persistent cluster kernel.
+//
+// Workgroup w owns hidden indices / context dims J_w = D_w = [32w, 32w+32), prenet columns [32w,+32) (dense_1) and
+// [16w,+16) (dense_2); it keeps the matching ROW slices of Wq, Whc, Whg, Wx, W2, W1c in registers ("transposed"
+// products: out[k in slice] = sum_j g[j] * W[k][j]) and memory[row][:, D_w], keys[row][:, D_w] in LDS.
+// Per step: da partials (all-reduce), dq, dcp, dg, dp2pre, dp1pre (all-gathers) = 6 exchanges.
+// The gradients wrt keys / memory / attention_v are NOT accumulated in the loop: the kernel saves de_s[t] and the total
+// dctx_s, and attn_hoisted_bwd_k reduces over s afterwards, fully parallel (dM = sum_s a_s (x) dctx_s; dK needs the tanh
+// tile recomputed per (s,t,d), which is why it cannot be a GEMM).
+// =====================================================================================================================
+// dot of this lane's K-part, both rows, weights = a contiguous ROW slice held in registers
+template <int LEN>
+__device__ __forceinline__ void gather2(const u64* regA, const u64* regB, float* lds0, float* lds1, int offA, int offB,
+                                        int w, unsigned epoch, int tid, int* err) {
+    // two published vectors of LEN values per row per workgroup gathered with ONE poll round trip (2 granules/thread)
+    constexpr int TOT = 2 * (CW - 1) * LEN;
+    if (tid < TOT) {
+        const int row = tid / ((CW - 1) * LEN), rem = tid - row * (CW - 1) * LEN;
+        const int peer = rem / LEN, jj = rem - peer * LEN;
+        const int pw = peer + (peer >= w ? 1 : 0);
+        const int j = pw * LEN + jj;
+        const u64* const ptr[2] = {regA + row * (CW * LEN) + j, regB + row * (CW * LEN) + j};
+        float val[2];
+        get_g<2>(ptr, epoch, val, err);
+        float* l = row ? lds1 : lds0;
+        l[PIDX(offA + j)] = val[0];
+        l[PIDX(offB + j)] = val[1];
+    }
+}
+template <int LEN>
+__device__ __forceinline__ void gather_off(const u64* region, float* lds0, float* lds1, int off, int w, unsigned epoch,
+                                           int tid, int* err) {
+    constexpr int TOT = 2 * (CW - 1) * LEN;
+    if (tid < TOT) {
+        const int row = tid / ((CW - 1) * LEN), rem = tid - row * (CW - 1) * LEN;
+        const int peer = rem / LEN, jj = rem - peer * LEN;
+        const int pw = peer + (peer >= w ? 1 : 0);
+        const int j = pw * LEN + jj;
+        const u64* const ptr[1] = {region + row * (CW * LEN) + j};
+        float val[1];
+        get_g<1>(ptr, epoch, val, err);
+        (row ? lds1 : lds0)[PIDX(off + j)] = val[0];
+    }
+}
+
+__global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int nclus = gridDim.x / CW;
+    int w, cl;
+    if ((nclus & 7) == 0) { const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3; w = qq & 7; cl = (qq >> 3) * 8 + xcd; }
+    else { w = blockIdx.x & 7; cl = blockIdx.x >> 3; }
+    const int Ti = p.Ti, S = p.S;
+    const int row0 = cl * 2;
+    const bool ok[2] = {row0 < p.N, row0 + 1 < p.N};
+    const long rw[2] = {(long)min(row0, p.N - 1), (long)min(row0 + 1, p.N - 1)};
+
+    float* dq_l = smem;                            // [2][PLEN(256)]
+    float* dxp_l = dq_l + 2 * PLEN(256);           // [2][PLEN(768)]: dg_r(256) | dg_u(256) | dcp(256)
+    float* dp2_l = dxp_l + 2 * PLEN(768);          // [2][PLEN(128)]
+    float* dp1_l = dp2_l + 2 * PLEN(128);          // [2][PLEN(256)]
+    float* dctx_l = dp1_l + 2 * PLEN(256);         // [2][32]
+    float* q_l = dctx_l + 64;                      // [2][32]
+    float* ep_l = q_l + 64;                        // [2*Ti] own da partials
+    float* a_l = ep_l + ((2 * Ti + 3) & ~3);       // [2*Ti] alignments of this step
+    float* de_l = a_l + ((2 * Ti + 3) & ~3);       // [2*Ti] da -> de
+    float* cp_l = de_l + ((2 * Ti + 3) & ~3);      // [8][64]
+    float* K_l = cp_l + 512;
+    float* M_l = K_l + 2 * Ti * 32;
+    for (int i = tid; i < 2 * Ti * 8; i += AT) {
+        const int c4 = i & 7, t = (i >> 3) % Ti, row = (i >> 3) / Ti;
+        const long g = ((rw[row] * Ti) + t) * 256 + 32 * w + c4 * 4;
+        *reinterpret_cast<float4*>(K_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.keys + g);
+        *reinterpret_cast<float4*>(M_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.mem + g);
+    }
+
+    // ---- register-resident ROW slices (K split over lanes)
+    const int cA = tid >> 4, pA = tid & 15;     // 32 outputs x 16 parts
+    const int cB = tid >> 5, pB = tid & 31;     // 16 outputs x 32 parts
+    const int jA = 32 * w + cA;                 // hidden / ctx / prenet-1 index of the A mapping
+    const int jB = 16 * w + cB;                 // prenet-2 index
+    float wq[16], wc[16], wg[32], wx[24], w2[8], w1[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wq[k] = p.wq[(long)jA * 256 + pA * 16 + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wc[k] = p.whc[(long)jA * 256 + pA * 16 + k];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wg[k] = p.whg[(long)jA * 512 + pA * 32 + k];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) wx[k] = p.wx[(long)jB * 768 + pB * 24 + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w2[k] = p.w2[(long)jA * 128 + pA * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w1[k] = p.w1c[(long)jA * 256 + pA * 16 + k];
+    const float vd = p.v[32 * w + (tid & 31)];            // dq mapping: d = tid & 31
+
+    // exchange regions: DA [8][2Ti]; DQ, DCP [2][256]; DGR, DGU [2][256]; DP2 [2][128]; DP1 [2][256]
+    const long per_clu = (long)CW * 2 * Ti + 2 * 256 * 5 + 2 * 128;
+    u64* X = p.xchg + (long)cl * per_clu;
+    u64 *xDQ = X, *xDCP = X + 512, *xDGR = X + 1024, *xDGU = X + 1536, *xDP2 = X + 2048, *xDP1 = X + 2304, *xDA = X + 2816;
+
+    float dhc0 = 0.f, dhc1 = 0.f;      // dh carry   (owner lanes: pA == 0, index jA)
+    float dcc0 = 0.f, dcc1 = 0.f;      // dctx carry (owner lanes: pA == 0, index jA)
+    __syncthreads();
+
+    for (int s = S - 1; s >= 0; --s) {
+        const unsigned epoch = (unsigned)(S - s);
+        const long so[2] = {rw[0] * S + s, rw[1] * S + s};
+        // ---- prefetch this step's saved activations / external gradients
+        for (int i = tid; i < 2 * Ti; i += AT) { const int row = i >= Ti; a_l[i] = p.align[so[row] * Ti + (i - row * Ti)]; }
+        if (tid < 64) q_l[tid] = p.q[so[tid >> 5] * 256 + 32 * w + (tid & 31)];
+        float r_[2] = {0, 0}, u_[2] = {0, 0}, c_[2] = {0, 0}, hp_[2] = {0, 0}, dhe[2] = {0, 0}, dce[2] = {0, 0}, p1v[2] = {0, 0};
+        float p2v[2] = {0, 0};
+        if (pA == 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                r_[b] = p.r[so[b] * 256 + jA]; u_[b] = p.u[so[b] * 256 + jA]; c_[b] = p.c[so[b] * 256 + jA];
+                hp_[b] = s > 0 ? p.hc[(so[b] - 1) * 512 + jA] : 0.f;
+                dhe[b] = p.dhc[so[b] * 512 + jA]; dce[b] = p.dhc[so[b] * 512 + 256 + jA];
+                p1v[b] = p.p1[so[b] * 256 + jA];
+            }
+        }
+        if (pB == 0) { p2v[0] = p.p2[so[0] * 128 + jB]; p2v[1] = p.p2[so[1] * 128 + jB]; }
+        // ================= X1: total dctx (own slice), da partials =================
+        if (pA == 0) {
+            const float d0 = dce[0] + dcc0, d1 = dce[1] + dcc1;
+            dctx_l[cA] = d0; dctx_l[32 + cA] = d1;
+            if (ok[0]) p.dctx[so[0] * 256 + jA] = d0;
+            if (ok[1]) p.dctx[so[1] * 256 + jA] = d1;
+        }
+        __syncthreads();
+        for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
+            const int half = tid & 1, row = i >= Ti;
+            const float* mp = M_l + i * 32 + half * 16;
+            const float* gp = dctx_l + row * 32 + half * 16;
+            float e = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const float4 mv = *reinterpret_cast<const float4*>(mp + d4 * 4);
+                const float4 gv = *reinterpret_cast<const float4*>(gp + d4 * 4);
+                e = fmaf(mv.x, gv.x, e); e = fmaf(mv.y, gv.y, e); e = fmaf(mv.z, gv.z, e); e = fmaf(mv.w, gv.w, e);
+            }
+            e += __shfl_xor(e, 1, 64);
+            if (half == 0) { ep_l[i] = e; put_g(xDA + (long)w * 2 * Ti + i, epoch, e); }
+        }
+        __syncthreads();
+        for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
+            const int half = tid & 1;
+            float val[4];
+            const u64* ptr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pw = half * 4 + k;
+                ptr[k] = xDA + (long)(pw == w ? ((w + 1) & 7) : pw) * 2 * Ti + i;
+            }
+            const u64* const cptr[4] = {ptr[0], ptr[1], ptr[2], ptr[3]};
+            get_g<4>(cptr, epoch, val, p.err);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? ep_l[i] : val[k];
+            const float other = __shfl_xor(sum, 1, 64);
+            if (half == 0) de_l[i] = sum + other;                 // da[row][t]
+        }
+        __syncthreads();
+        // ================= X2: softmax backward: de = a * (da - sum a*da) =================
+        if (tid < 128) {
+            const int row = tid >> 6, lane = tid & 63;
+            float* dr_ = de_l + row * Ti;
+            const float* ar = a_l + row * Ti;
+            float dot = 0.f;
+            for (int t = lane; t < Ti; t += 64) dot = fmaf(ar[t], dr_[t], dot);
+            dot = wave_sum(dot);
+            for (int t = lane; t < Ti; t += 64) dr_[t] = ar[t] * (dr_[t] - dot);
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * Ti; i += AT) {
+            const int row = i >= Ti, t = i - row * Ti;
+            if ((t & 7) == w && ok[row]) p.de[so[row] * Ti + t] = de_l[i];
+        }
+        // ================= X3: dq slice: dq[d] = v_d * sum_t de[t] * (1 - tanh^2(K[t,d] + q[d])) =================
+        {
+            const int row = tid >> 8, tp = (tid >> 5) & 7, d = tid & 31;
+            const float* er = de_l + row * Ti;
+            const float* kr = K_l + row * Ti * 32 + d;
+            const float qd = q_l[row * 32 + d];
+            float acc = 0.f;
+            for (int t = tp; t < Ti; t += 8) { const float th = fast_tanh_(kr[t * 32] + qd); acc = fmaf(er[t], 1.f - th * th, acc); }
+            cp_l[tp * 64 + row * 32 + d] = acc * vd;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int row = tid >> 5, d = tid & 31, j = 32 * w + d;
+            float x = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 8; ++tp) x += cp_l[tp * 64 + tid];
+            dq_l[row * PLEN(256) + PIDX(j)] = x;
+            put_g(xDQ + row * 256 + j, epoch, x);
+            if (ok[row]) p.dq[so[row] * 256 + j] = x;
+        }
+        gather_vec<32>(xDQ, dq_l, dq_l + PLEN(256), w, epoch, tid, p.err);
+        __syncthreads();
+        // ================= X4: dhT = dh_ext + carry + dq . Wq^T ; candidate pre-activation gradient =================
+        float dhT[2] = {0, 0}, du[2] = {0, 0}, dhd[2] = {0, 0};
+        {
+            float a0 = 0.f, a1 = 0.f;
+            dot2<16>(dq_l, dq_l + PLEN(256), pA * 16, wq, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) {
+                dhT[0] = a0 + dhe[0] + dhc0; dhT[1] = a1 + dhe[1] + dhc1;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    du[b] = dhT[b] * (hp_[b] - c_[b]);
+                    dhd[b] = dhT[b] * u_[b];
+                    const float dcp = dhT[b] * (1.f - u_[b]) * (1.f - c_[b] * c_[b]);
+                    dxp_l[b * PLEN(768) + PIDX(512 + jA)] = dcp;
+                    put_g(xDCP + b * 256 + jA, epoch, dcp);
+                    if (ok[b]) p.dxp[so[b] * 768 + 512 + jA] = dcp;
+                }
+            }
+            gather_off<32>(xDCP, dxp_l, dxp_l + PLEN(768), 512, w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= X5: drh = dcp . Whc^T ; gate pre-activation gradients =================
+        float dhp[2] = {0, 0};
+        {
+            float a0 = 0.f, a1 = 0.f;
+            dot2<16>(dxp_l + PIDX(512), dxp_l + PLEN(768) + PIDX(512), pA * 16, wc, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) {
+                const float drh[2] = {a0, a1};
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float dgr = drh[b] * hp_[b] * r_[b] * (1.f - r_[b]);
+                    const float dgu = du[b] * u_[b] * (1.f - u_[b]);
+                    dhp[b] = dhd[b] + drh[b] * r_[b];
+                    dxp_l[b * PLEN(768) + PIDX(jA)] = dgr;
+                    dxp_l[b * PLEN(768) + PIDX(256 + jA)] = dgu;
+                    put_g(xDGR + b * 256 + jA, epoch, dgr);
+                    put_g(xDGU + b * 256 + jA, epoch, dgu);
+                    if (ok[b]) { p.dxp[so[b] * 768 + jA] = dgr; p.dxp[so[b] * 768 + 256 + jA] = dgu; }
+                }
+            }
+            gather2<32>(xDGR, xDGU, dxp_l, dxp_l + PLEN(768), 0, 256, w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= X6: dh carry = dhp + dg . Whg^T ;  dp2pre = (dxp . Wx^T) * (p2 > 0) =================
+        {
+            float a0 = 0.f, a1 = 0.f;
+            dot2<32>(dxp_l, dxp_l + PLEN(768), pA * 32, wg, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) { dhc0 = dhp[0] + a0; dhc1 = dhp[1] + a1; }
+            float b0 = 0.f, b1 = 0.f;
+            dot2<24>(dxp_l, dxp_l + PLEN(768), pB * 24, wx, b0, b1);
+            b0 = lane_reduce<32>(b0); b1 = lane_reduce<32>(b1);
+            if (pB == 0) {
+                b0 = p2v[0] > 0.f ? b0 : 0.f; b1 = p2v[1] > 0.f ? b1 : 0.f;
+                dp2_l[PIDX(jB)] = b0; dp2_l[PLEN(128) + PIDX(jB)] = b1;
+                put_g(xDP2 + jB, epoch, b0); put_g(xDP2 + 128 + jB, epoch, b1);
+                if (ok[0]) p.dp2[so[0] * 128 + jB] = b0;
+                if (ok[1]) p.dp2[so[1] * 128 + jB] = b1;
+            }
+            gather_vec<16>(xDP2, dp2_l, dp2_l + PLEN(128), w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= X7: dp1pre = (dp2pre . W2^T) * (p1 > 0) =================
+        {
+            float a0 = 0.f, a1 = 0.f;
+            dot2<8>(dp2_l, dp2_l + PLEN(128), pA * 8, w2, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) {
+                a0 = p1v[0] > 0.f ? a0 : 0.f; a1 = p1v[1] > 0.f ? a1 : 0.f;
+                dp1_l[PIDX(jA)] = a0; dp1_l[PLEN(256) + PIDX(jA)] = a1;
+                put_g(xDP1 + jA, epoch, a0); put_g(xDP1 + 256 + jA, epoch, a1);
+                if (ok[0]) p.dp1[so[0] * 256 + jA] = a0;
+                if (ok[1]) p.dp1[so[1] * 256 + jA] = a1;
+            }
+            gather_vec<32>(xDP1, dp1_l, dp1_l + PLEN(256), w, epoch, tid, p.err);
+        }
+        __syncthreads();
+        // ================= X8: dctx carry (gradient wrt ctx_{s-1}) = dp1pre . W1c^T =================
+        {
+            float a0 = 0.f, a1 = 0.f;
+            dot2<16>(dp1_l, dp1_l + PLEN(256), pA * 16, w1, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) { dcc0 = a0; dcc1 = a1; }
+        }
+        // (the next iteration's first LDS writes -- a_l, q_l, dctx_l -- are not read by X8: no barrier needed here)
+    }
+}
+
+// Hoisted reductions over the S steps (fully parallel, one workgroup per (n,t), thread = feature d):
+//   dMEM[n,t,d]  = sum_s a[n,s,t] * dctx[n,s,d]                                   (gradient through the attention values)
+//   dKEYS[n,t,d] = v[d] * sum_s de[n,s,t] * (1 - tanh^2(keys[n,t,d] + q[n,s,d]))  (tanh tile recomputed, never stored)
+//   dvpart[n*Ti+t, d] = sum_s de[n,s,t] * tanh(...)                               (attention_v gradient partials)
+__global__ __launch_bounds__(256) void attn_hoisted_bwd_k(const float* __restrict__ keys, const float* __restrict__ q,
+                                                         const float* __restrict__ align, const float* __restrict__ de,
+                                                         const float* __restrict__ dctx, const float* __restrict__ v,
+                                                         float* __restrict__ dkeys, float* __restrict__ dmem,
+                                                         float* __restrict__ dvpart, int S, int Ti) {
+    const int n = blockIdx.y, t = blockIdx.x, d = threadIdx.x;
+    const long nt = (long)n * Ti + t;
+    const float kd = keys[nt * 256 + d];
+    float am = 0.f, ak = 0.f, av = 0.f;
+    const float* ap = align + (long)n * S * Ti + t;
+    const float* ep = de + (long)n * S * Ti + t;
+    const float* qp = q + (long)n * S * 256 + d;
+    const float* cp = dctx + (long)n * S * 256 + d;
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {
+        const float a = ap[(long)s * Ti], e = ep[(long)s * Ti];
+        const float th = fast_tanh_(kd + qp[(long)s * 256]);
+        am = fmaf(a, cp[(long)s * 256], am);
+        ak = fmaf(e, 1.f - th * th, ak);
+        av = fmaf(e, th, av);
+    }
+    dmem[nt * 256 + d] = am;
+    dkeys[nt * 256 + d] = ak * v[d];
+    dvpart[nt * 256 + d] = av;
+}
+
+static size_t attn_cluster_bwd_smem(int Ti) {
+    size_t f = 2 * PLEN(256) + 2 * PLEN(768) + 2 * PLEN(128) + 2 * PLEN(256) + 64 + 64 + 3 * ((2 * Ti + 3) & ~3) + 512 +
+               (size_t)4 * Ti * 32;
+    return f * sizeof(float);
+}
+
+extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
+    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128);
+}
+
+int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attn_cluster_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return TACO_EINVAL;
+        attr_set = true;
+    }
+    if (attn_cluster_bwd_smem(p.Ti) > 160 * 1024) return TACO_EINVAL;
+    if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    hipLaunchKernelGGL(attn_cluster_bwd_k, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti), st, p);
+    hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3(p.Ti, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v, dkeys,
+                       dmem, dvpart, p.S, p.Ti);
+    TACO_RETURN_LAST();
+}

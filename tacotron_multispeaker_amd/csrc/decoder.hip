@@ -16,7 +16,7 @@
 // reductions; the softmax over ALL Ti positions (no memory mask, A.7) is a workgroup reduction.
 //
 // All per-step tensors are laid out [N, S, dim] (row stride S*dim) so the hoisted GEMMs see plain matrices.
-#include "common.hpp"
+#include "attn_cluster.hpp"
 
 // ---------------------------------------------------------------------------------------------------
 // skinny GEMM: out[M<=32 rows/tile, 16 cols/workgroup] = sum over up to 2 (A,B) segments, K split over 8 waves
@@ -357,7 +357,7 @@ extern "C" int taco_gather_frames(const float* mel, float* frames, int N, int S,
 // ---------------------------------------------------------------------------------------------------
 // host-side step loops
 // ---------------------------------------------------------------------------------------------------
-extern "C" int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t st) {
+static int attn_rnn_fwd_steps(const void* const* ptrs, const int* dims, hipStream_t st) {
     if (!ptrs || !dims) return TACO_EINVAL;
     const int N = dims[0], S = dims[1], Ti = dims[2];
     if (N <= 0 || S <= 0 || Ti <= 0) return TACO_EINVAL;
@@ -412,7 +412,7 @@ extern "C" int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipSt
 // BPTT of the attention recurrence.  dHC [N,S,512] holds the external gradients wrt (h_s, ctx_s) from the
 // concat projection.  Produces dXP (attention GRU pre-activations) [N,S,768], dP2/dP1 (prenet pre-activations),
 // dQ [N,S,256] (pre-zeroed), dKEYS / dMEM [N,Ti,256] (pre-zeroed accumulators), dVPART [N,ceil(Ti/16),256] (pre-zeroed).
-extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t st) {
+static int attn_rnn_bwd_steps(const void* const* ptrs, const int* dims, hipStream_t st) {
     if (!ptrs || !dims) return TACO_EINVAL;
     const int N = dims[0], S = dims[1], Ti = dims[2];
     if (N <= 0 || S <= 0 || Ti <= 0) return TACO_EINVAL;
@@ -475,4 +475,51 @@ extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipSt
         }
     }
     TACO_RETURN_LAST();
+}
+
+extern "C" int taco_attn_cluster_supported(int N, int Ti);
+
+// Attention recurrence, forward: one persistent cluster launch (attn_cluster.hip) when the shape fits
+// (N <= 64, T_in slices fit LDS) and scratch was provided, else one launch per dependent stage.
+extern "C" int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t st) {
+    if (!ptrs || !dims) return TACO_EINVAL;
+    const int N = dims[0], S = dims[1], Ti = dims[2];
+    if (N <= 0 || S <= 0 || Ti <= 0) return TACO_EINVAL;
+    if (ptrs[TACO_AP_XCHG] && ptrs[TACO_AP_ERR] && taco_attn_cluster_supported(N, Ti)) {
+        auto F = [&](int i) { return (const float*)ptrs[i]; };
+        auto G = [&](int i) { return (float*)const_cast<void*>(ptrs[i]); };
+        AttnClu p{};
+        p.w1c = F(TACO_AP_W1C); p.f1 = F(TACO_AP_F1); p.w2 = F(TACO_AP_W2); p.b2 = F(TACO_AP_B2); p.wx = F(TACO_AP_WX);
+        p.whg = F(TACO_AP_WHG); p.whc = F(TACO_AP_WHC); p.bg = F(TACO_AP_BG); p.wq = F(TACO_AP_WQ); p.v = F(TACO_AP_V);
+        p.keys = F(TACO_AP_KEYS); p.mem = F(TACO_AP_MEM);
+        p.p1 = G(TACO_AP_P1); p.p2 = G(TACO_AP_P2); p.r = G(TACO_AP_R); p.u = G(TACO_AP_U); p.c = G(TACO_AP_C);
+        p.rh = G(TACO_AP_RH); p.hc = G(TACO_AP_HC); p.q = G(TACO_AP_Q); p.align = G(TACO_AP_ALIGN);
+        p.xchg = (u64*)const_cast<void*>(ptrs[TACO_AP_XCHG]); p.err = (int*)const_cast<void*>(ptrs[TACO_AP_ERR]);
+        p.N = N; p.S = S; p.Ti = Ti;
+        return attn_cluster_fwd_launch(p, st);
+    }
+    return attn_rnn_fwd_steps(ptrs, dims, st);
+}
+
+// Attention recurrence, backward.  Cluster path: also needs TACO_AP_DE [N,S,Ti], TACO_AP_DCTXS [N,S,256] and a dVPART of
+// [N*Ti,256]; dKEYS / dMEM / dVPART are then WRITTEN (not accumulated) by the hoisted reduction kernel.
+extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t st) {
+    if (!ptrs || !dims) return TACO_EINVAL;
+    const int N = dims[0], S = dims[1], Ti = dims[2];
+    if (N <= 0 || S <= 0 || Ti <= 0) return TACO_EINVAL;
+    if (ptrs[TACO_AP_XCHG] && ptrs[TACO_AP_ERR] && ptrs[TACO_AP_DE] && ptrs[TACO_AP_DCTXS] && taco_attn_cluster_supported(N, Ti)) {
+        auto F = [&](int i) { return (const float*)ptrs[i]; };
+        auto G = [&](int i) { return (float*)const_cast<void*>(ptrs[i]); };
+        AttnCluB p{};
+        p.w1c = F(TACO_AP_W1C); p.w2 = F(TACO_AP_W2); p.wx = F(TACO_AP_WX); p.whg = F(TACO_AP_WHG); p.whc = F(TACO_AP_WHC);
+        p.wq = F(TACO_AP_WQ); p.v = F(TACO_AP_V); p.keys = F(TACO_AP_KEYS); p.mem = F(TACO_AP_MEM);
+        p.p1 = F(TACO_AP_P1); p.p2 = F(TACO_AP_P2); p.r = F(TACO_AP_R); p.u = F(TACO_AP_U); p.c = F(TACO_AP_C);
+        p.hc = F(TACO_AP_HC); p.q = F(TACO_AP_Q); p.align = F(TACO_AP_ALIGN); p.dhc = F(TACO_AP_DHC);
+        p.dxp = G(TACO_AP_DXP); p.dp2 = G(TACO_AP_DP2); p.dp1 = G(TACO_AP_DP1); p.dq = G(TACO_AP_DQ);
+        p.de = G(TACO_AP_DE); p.dctx = G(TACO_AP_DCTXS);
+        p.xchg = (u64*)const_cast<void*>(ptrs[TACO_AP_XCHG]); p.err = (int*)const_cast<void*>(ptrs[TACO_AP_ERR]);
+        p.N = N; p.S = S; p.Ti = Ti;
+        return attn_cluster_bwd_launch(p, G(TACO_AP_DKEYS), G(TACO_AP_DMEM), G(TACO_AP_DVPART), st);
+    }
+    return attn_rnn_bwd_steps(ptrs, dims, st);
 }

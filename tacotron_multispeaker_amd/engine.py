@@ -23,7 +23,7 @@ ACT_NONE, ACT_RELU = 0, 1
 # slots of the attention pointer table (enum TacoAttnPtr in include/taco_hip.h)
 _AP = ['W1C', 'F1', 'W2', 'B2', 'WX', 'WHG', 'WHC', 'BG', 'WQ', 'V', 'KEYS', 'MEM', 'ZEROS', 'P1', 'P2', 'R', 'U', 'C',
        'RH', 'HC', 'Q', 'ALIGN', 'DHC', 'DXP', 'DP2', 'DP1', 'DQ', 'DKEYS', 'DMEM', 'DVPART', 'DA', 'DHT', 'DHPART',
-       'DHCARRY', 'DCTX', 'DCTXCARRY']
+       'DHCARRY', 'DCTX', 'DCTXCARRY', 'XCHG', 'ERR', 'DE', 'DCTXS']
 AP = {n: i for i, n in enumerate(_AP)}
 
 
@@ -299,6 +299,10 @@ class Engine:
         self.encoder_outputs = ENC.view(N, Ti, 256)
         return MEL, LIN, self.alignments
 
+    def _attn_slots(self, N, Ti):
+        dll = lib.load()
+        return max(dll.taco_attn_cluster_xchg_slots(N, Ti), dll.taco_attn_cluster_bwd_xchg_slots(N, Ti))
+
     def _make_attn_ptrs(self, N, S, Ti):
         b = self.buf
         W1 = self.P('decoder_prenet/dense_1/kernel')
@@ -313,9 +317,11 @@ class Engine:
             'ALIGN': b('ALIGN', N * S, Ti),
             'DHC': b('dHC', N * S, 512), 'DXP': b('dXPa', N * S, 768), 'DP2': b('dP2', N * S, 128), 'DP1': b('dP1', N * S, 256),
             'DQ': b('dQ', N * S, 256), 'DKEYS': b('dKEYS', N * Ti, 256), 'DMEM': b('dMEM', N * Ti, 256),
-            'DVPART': b('dVPART', N * ((Ti + 15) // 16), 256), 'DA': b('dA', N * Ti), 'DHT': b('dHT', N, 256),
+            'DVPART': b('dVPART', N * Ti, 256), 'DA': b('dA', N * Ti), 'DHT': b('dHT', N, 256),
             'DHPART': b('dHPART', N, 256), 'DHCARRY': b('dHCARRY', N, 256), 'DCTX': b('dCTX', N, 256),
             'DCTXCARRY': b('dCTXCARRY', N, 256),
+            'XCHG': b('xchg_attn', max(self._attn_slots(N, Ti), 8), dtype=torch.int64), 'ERR': self.err,
+            'DE': b('dE', N * S, Ti), 'DCTXS': b('dCTXS', N * S, 256),
         }
         arr = (ctypes.c_void_p * len(_AP))(*[t[n].data_ptr() for n in _AP])
         self._attn_dims = (ctypes.c_int * 3)(N, S, Ti)
@@ -392,8 +398,7 @@ class Engine:
         self.gemm_dw_shift(HC, dXPa, self.G('attention_gru/whg'), Ms, S, 256, 512, 512, 768, 512)
         self.gemm_dw(b['aRH'], dXPa[:, 512:], self.G('attention_gru/whc'), Ms, 256, 256, ldx=256, lddy=768, ldw=256)
         self.gemm_dw(HC, dQ, self.G('attention/query_layer/kernel'), Ms, 256, 256, ldx=512)
-        nch = (Ti + 15) // 16
-        self.colsum(b['dVPART'], self.G('attention/attention_v'), N * nch, 256)
+        self.colsum(b['dVPART'], self.G('attention/attention_v'), N * Ti, 256)      # rows unused by the per-step path stay 0
         self.gemm_dw(b['P1'], dP2, self.G('decoder_prenet/dense_2/kernel'), Ms, 256, 128)
         self.colsum(dP2, self.G('decoder_prenet/dense_2/bias'), Ms, 128)
         dW1 = self.G('decoder_prenet/dense_1/kernel')
