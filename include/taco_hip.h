@@ -60,10 +60,10 @@ int taco_bn_infer_params(const float* moving_mean, const float* moving_var, cons
 int taco_bn_apply_fwd(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldr, float* y,
                       int ldy, int M, int C, int T, int pool, hipStream_t stream);
 /* dy = gradient wrt the BN output (pool=1: wrt the pooled output); dx = gradient wrt the conv pre-activation
- * (relu=1 applies the conv's ReLU mask); dgamma/dbeta are ADDED */
+ * (relu=1 applies the conv's ReLU mask); dgamma/dbeta and the conv bias gradient dbias[c] = sum_m dx[m,c] are ADDED */
 int taco_bn_bwd(const float* x, int ldx, const float* dy, int lddy, const float* mean, const float* rstd,
                 const float* scale, const float* shift, const float* gamma, double* dstat_zeroed, float* dgamma,
-                float* dbeta, float* dx, int lddx, int M, int C, int T, int pool, int relu, hipStream_t stream);
+                float* dbeta, float* dbias, float* dx, int lddx, int M, int C, int T, int pool, int relu, hipStream_t stream);
 
 /* ---- highway gating (models/modules.py:77-90); Z [M,256] = x.[W_H|W_T]+b in, [relu(H), sigmoid(T)] out -------- */
 int taco_highway_gate_fwd(float* Z, const float* x, float* y, int M, hipStream_t stream);

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void col_reduce_k(ColRed p) {
         sc = *reinterpret_cast<const float4*>(p.scale + c);
         sh = *reinterpret_cast<const float4*>(p.shift + c);
     }
-    if (active)
-        for (long m = r0 + ty; m < r1; m += 4) {
+    if (active) {
+        auto body = [&](long m) {
             const float4 xv = *reinterpret_cast<const float4*>(p.x + m * p.ldx + c);
             if (MODE == 0) { s0.x += xv.x; s0.y += xv.y; s0.z += xv.z; s0.w += xv.w; }
             else if (MODE == 1) {
@@ -137,7 +137,11 @@ __global__ __launch_bounds__(256) void col_reduce_k(ColRed p) {
                 s1.x += g.x * (xv.x - mu.x) * rs.x; s1.y += g.y * (xv.y - mu.y) * rs.y;
                 s1.z += g.z * (xv.z - mu.z) * rs.z; s1.w += g.w * (xv.w - mu.w) * rs.w;
             }
-        }
+        };
+        long m = r0 + ty;
+        for (; m + 12 < r1; m += 16) { body(m); body(m + 4); body(m + 8); body(m + 12); }   // 4 independent loads in flight
+        for (; m < r1; m += 4) body(m);
+    }
     __shared__ float4 red[2][4][64];
     red[0][ty][tx] = s0; red[1][ty][tx] = s1;
     __syncthreads();
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(256) void col_reduce_k(ColRed p) {
 
 static void col_reduce_grid(int M, int C, dim3& g, int& rpb) {
     const int gx = cdiv(C, 256);
-    int gy = cdiv(2048, gx);
-    rpb = cdiv(M, gy);
-    if (rpb < 16) rpb = 16;
+    int gy = cdiv(768, gx);              // ~768 workgroups: enough to fill 256 CUs, few enough to keep the final
+    rpb = cdiv(M, gy);                   // per-column atomics (one set per workgroup) off the contention cliff
+    if (rpb < 64) rpb = 64;
     rpb = (rpb + 3) & ~3;
     gy = cdiv(M, rpb);
     g = dim3(gx, gy);
@@ -224,41 +228,57 @@ __global__ void bn_apply_k(const float* __restrict__ x, int ldx, const float* __
 // Also emits dgamma = sum(db*xhat), dbeta = sum(db) (block 0 only, ADDED into the gradient buffers).
 struct BnBwd {
     ColRed r;  // x, dy, mean, rstd, scale, shift, dstat (sums from col_reduce MODE 2), M, C, T, pool
-    const float* gamma; float* dgamma; float* dbeta; float* dx; int lddx; int relu;
+    const float* gamma; float* dgamma; float* dbeta; float* dbias; float* dx; int lddx; int relu;
 };
-__global__ void bn_bwd_apply_k(BnBwd p) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwd p) {
+    // thread = one float4 column group (64 per workgroup = 256 columns), 4 row lanes; rows [r0, r1) of this workgroup
     const ColRed& q = p.r;
-    const int c4n = q.C / 4;
-    const long total = (long)q.M * c4n;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + tx) * 4;
+    const bool active = c < q.C;
+    const long r0 = (long)blockIdx.y * q.rows_per_block;
+    const long r1 = min((long)q.M, r0 + q.rows_per_block);
     const float invM = 1.0f / (float)q.M;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c4n) * 4;
-        const long m = idx / c4n;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
         const float4 sc = *reinterpret_cast<const float4*>(q.scale + c);
         const float4 sh = *reinterpret_cast<const float4*>(q.shift + c);
         const float4 mu = *reinterpret_cast<const float4*>(q.mean + c);
         const float4 rs = *reinterpret_cast<const float4*>(q.rstd + c);
-        const float4 xv = *reinterpret_cast<const float4*>(q.x + m * q.ldx + c);
-        const float4 g = bn_out_grad(q, m, c, xv, sc, sh);
         const float sdb[4] = {(float)q.dstat[c], (float)q.dstat[c + 1], (float)q.dstat[c + 2], (float)q.dstat[c + 3]};
         const float sdx[4] = {(float)q.dstat[q.C + c], (float)q.dstat[q.C + c + 1], (float)q.dstat[q.C + c + 2], (float)q.dstat[q.C + c + 3]};
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g.x, g.y, g.z, g.w};
         const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w}, scs[4] = {sc.x, sc.y, sc.z, sc.w};
-        float o[4];
+        for (long m = r0 + ty; m < r1; m += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(q.x + m * q.ldx + c);
+            const float4 g = bn_out_grad(q, m, c, xv, sc, sh);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g.x, g.y, g.z, g.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xs[k] - mus[k]) * rss[k];
+                float d = scs[k] * (gs[k] - sdb[k] * invM - xh * sdx[k] * invM);
+                if (p.relu && !(xs[k] > 0.0f)) d = 0.0f;
+                o[k] = d;
+                bs[k] += d;
+            }
+            *reinterpret_cast<float4*>(p.dx + m * p.lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __shared__ float red[4][4][64];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][ty][tx] = bs[k];
+    __syncthreads();
+    if (ty == 0 && active) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float xh = (xs[k] - mus[k]) * rss[k];
-            float d = scs[k] * (gs[k] - sdb[k] * invM - xh * sdx[k] * invM);
-            if (p.relu && !(xs[k] > 0.0f)) d = 0.0f;
-            o[k] = d;
+            const float t = red[k][0][tx] + red[k][1][tx] + red[k][2][tx] + red[k][3][tx];
+            if (p.dbias) atomicAdd(p.dbias + c + k, t);              // conv bias gradient = sum_m dx[m, c]
+            if (blockIdx.y == 0) {
+                p.dgamma[c + k] += (float)q.dstat[q.C + c + k];
+                p.dbeta[c + k] += (float)q.dstat[c + k];
+            }
         }
-        *reinterpret_cast<float4*>(p.dx + m * p.lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < q.C; c += blockDim.x) {
-            p.dgamma[c] += (float)q.dstat[q.C + c];
-            p.dbeta[c] += (float)q.dstat[c];
-        }
 }
 
 // =====================================================================================================
@@ -333,21 +353,27 @@ __global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, 
 // =====================================================================================================
 __global__ void l1_loss_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt, float* __restrict__ grad, int ldg,
                           double* __restrict__ sums, long rows, int C, int npri, float w_all, float w_pri) {
-    const long total = rows * ldg;
+    const int g4 = ldg >> 2;                        // float4 groups per (padded) row
+    const long total = rows * g4;
     float s_all = 0.f, s_pri = 0.f;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % ldg);
-        const long r = idx / ldg;
-        float g = 0.f;
-        if (c < C) {
-            const float d = out[r * ldo + c] - tgt[r * ldt + c];
-            const float a = fabsf(d);
-            s_all += a;
-            float w = w_all;
-            if (c < npri) { s_pri += a; w += w_pri; }
-            g = d > 0.f ? w : (d < 0.f ? -w : 0.f);
+        const long r = idx / g4;
+        const int c0 = (int)(idx - r * g4) * 4;
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            g[k] = 0.f;
+            if (c < C) {
+                const float d = out[r * ldo + c] - tgt[r * ldt + c];
+                const float a = fabsf(d);
+                s_all += a;
+                float w = w_all;
+                if (c < npri) { s_pri += a; w += w_pri; }
+                g[k] = d > 0.f ? w : (d < 0.f ? -w : 0.f);
+            }
         }
-        if (grad) grad[idx] = g;
+        if (grad) *reinterpret_cast<float4*>(grad + r * ldg + c0) = make_float4(g[0], g[1], g[2], g[3]);
     }
     const double a = wave_sum_d((double)s_all), b = wave_sum_d((double)s_pri);
     if ((threadIdx.x & 63) == 0) { atomicAdd(sums, a); atomicAdd(sums + 1, b); }
@@ -420,7 +446,8 @@ extern "C" int taco_bn_apply_fwd(const float* x, int ldx, const float* scale, co
 
 extern "C" int taco_bn_bwd(const float* x, int ldx, const float* dy, int lddy, const float* mean, const float* rstd,
                            const float* scale, const float* shift, const float* gamma, double* dstat_zeroed, float* dgamma,
-                           float* dbeta, float* dx, int lddx, int M, int C, int T, int pool, int relu, hipStream_t stream) {
+                           float* dbeta, float* dbias, float* dx, int lddx, int M, int C, int T, int pool, int relu,
+                           hipStream_t stream) {
     if (!x || !dy || !dx || !dstat_zeroed || (C & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || M % T) return TACO_EINVAL;
     BnBwd b{};
     ColRed& p = b.r;
@@ -428,8 +455,8 @@ extern "C" int taco_bn_bwd(const float* x, int ldx, const float* dy, int lddy, c
     p.dstat = dstat_zeroed; p.M = M; p.C = C; p.T = T; p.pool = pool;
     dim3 g; col_reduce_grid(M, C, g, p.rows_per_block);
     hipLaunchKernelGGL(col_reduce_k<2>, g, dim3(256), 0, stream, p);
-    b.gamma = gamma; b.dgamma = dgamma; b.dbeta = dbeta; b.dx = dx; b.lddx = lddx; b.relu = relu;
-    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(grid_for((long)M * C / 4)), dim3(256), 0, stream, b);
+    b.gamma = gamma; b.dgamma = dgamma; b.dbeta = dbeta; b.dbias = dbias; b.dx = dx; b.lddx = lddx; b.relu = relu;
+    hipLaunchKernelGGL(bn_bwd_apply_k, g, dim3(256), 0, stream, b);
     TACO_RETURN_LAST();
 }
 
@@ -457,7 +484,7 @@ extern "C" int taco_add(const float* a, const float* b, float* y, long n, int ac
 
 extern "C" int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2,
                             long rows, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
-    if (!out || !tgt || !sums2 || ldg < C) return TACO_EINVAL;
-    hipLaunchKernelGGL(l1_loss_k, dim3(grid_for(rows * ldg)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
+    if (!out || !tgt || !sums2 || ldg < C || (ldg & 3)) return TACO_EINVAL;
+    hipLaunchKernelGGL(l1_loss_k, dim3(grid_for(rows * (ldg / 4))), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
     TACO_RETURN_LAST();
 }

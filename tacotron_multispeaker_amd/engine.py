@@ -54,6 +54,9 @@ class Engine:
         self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._bufs = {}
         self._dpos = 0
+        self.side_stream = torch.cuda.Stream(device=self.dev)
+        self._side_active = False
+        self.overlap_wgrad = True
         self.world = 1
         self.load_named(named_params if named_params is not None else init_named(L, seed))
 
@@ -114,15 +117,27 @@ class Engine:
         lib.taco_conv_gemm_bwd_data(dY, W, dX, M, T or M, Cin, Cout, kw, bank,
                                     lddy or dY.stride(-2), ldw or Cout, lddx or dX.stride(-2), acc, self.st)
 
+    # Weight / bias gradients only feed the flat gradient buffer, so during backward they are enqueued on a SIDE
+    # stream (forked from / joined to the main stream with events; captured as a parallel branch of the HIP graph)
+    # and fill the CUs that the latency-bound persistent recurrence kernels leave idle.
+    def _side(self, fn):
+        if not self._side_active:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side_stream.wait_event(ev)
+        with torch.cuda.stream(self.side_stream):
+            fn()
+
     def gemm_dw(self, X, dY, dW, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, lddy=None, ldw=None):
-        lib.taco_conv_gemm_bwd_weight(X, dY, dW, M, T or M, Cin, Cout, kw, bank,
-                                      ldx or X.stride(-2), lddy or dY.stride(-2), ldw or Cout, self.st)
+        self._side(lambda: lib.taco_conv_gemm_bwd_weight(X, dY, dW, M, T or M, Cin, Cout, kw, bank,
+                                                         ldx or X.stride(-2), lddy or dY.stride(-2), ldw or Cout, self.st))
 
     def gemm_dw_shift(self, X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift=-1):
-        lib.taco_gemm_tn_shift(X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift, self.st)
+        self._side(lambda: lib.taco_gemm_tn_shift(X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift, self.st))
 
     def colsum(self, x, out, M, C, ldx=None):
-        lib.taco_col_sum(x, ldx or x.stride(-2), out, M, C, self.st)
+        self._side(lambda: lib.taco_col_sum(x, ldx or x.stride(-2), out, M, C, self.st))
 
     def dense_fwd(self, x, scope, y, M, cin, cout, act=0):
         self.gemm(x, self.P(scope + '/kernel'), self.P(scope + '/bias'), y, M, cin, cout, act=act)
@@ -152,7 +167,7 @@ class Engine:
         lib.taco_bn_bwd(x, x.stride(-2), dy, dy.stride(-2), self.L.bnview(self.bnbatch, scope + '/moving_mean'),
                         self.buf(scope + '/bn_rstd', C), self.buf(scope + '/bn_scale', C), self.buf(scope + '/bn_shift', C),
                         self.P(scope + '/gamma'), self.dslot(2 * C), self.G(scope + '/gamma'), self.G(scope + '/beta'),
-                        dx, dx.stride(-2), M, C, T, pool, relu, self.st)
+                        self.G(scope + '/bias'), dx, dx.stride(-2), M, C, T, pool, relu, self.st)
 
     # ---- CBHG (models/modules.py:35-74) ----------------------------------------------------------------------------
     def cbhg_fwd(self, sc, x, N, T, cin, K, proj, lengths, training):
@@ -209,9 +224,9 @@ class Engine:
             self.gemm_dw(RH[di], dXP[:, di * 384 + 256:], self.G('%s/bigru/%s_whc' % (sc, d)), M, 128, 128, ldx=128, lddy=768, ldw=128)
         dhw = self.buf(sc + '/dhw_a', M, 128)
         self.gemm_dx(dXP, self.P(sc + '/bigru/wx'), dhw, M, 128, 768)
-        dZ = self.buf(sc + '/dZ', M, 256)
         other = self.buf(sc + '/dhw_b', M, 128)
         for i in range(4, 0, -1):
+            dZ = self.buf('%s/dZ%d' % (sc, i), M, 256)      # one per layer: read later by the side-stream dW GEMM
             hw_in = b['%s/hw%d' % (sc, i - 1)] if i > 1 else (b[sc + '/hwd'] if proj[1] != 128 else b[sc + '/hw0'])
             lib.taco_highway_gate_bwd(b['%s/hwZ%d' % (sc, i)], hw_in, dhw, dZ, other, M, st)
             self.gemm_dw(hw_in, dZ, self.G('%s/highway_%d/kernel' % (sc, i)), M, 128, 256)
@@ -227,19 +242,16 @@ class Engine:
         dC2 = self.buf(sc + '/dc2', M, proj[1])
         self.bn_bwd(sc + '/proj_2', b[sc + '/c2'], dHW0, dC2, M, proj[1], T, 0, 0)
         self.gemm_dw(b[sc + '/y1'], dC2, self.G(sc + '/proj_2/kernel'), M, proj[0], proj[1], T=T, kw=3)
-        self.colsum(dC2, self.G(sc + '/proj_2/bias'), M, proj[1])
         dY1 = self.buf(sc + '/dy1', M, proj[0])
         self.gemm_dx(dC2, self.P(sc + '/proj_2/kernel'), dY1, M, proj[0], proj[1], T=T, kw=3)
         dC1 = self.buf(sc + '/dc1', M, proj[0])
         self.bn_bwd(sc + '/proj_1', b[sc + '/c1'], dY1, dC1, M, proj[0], T, 0, 1)
         self.gemm_dw(b[sc + '/pool'], dC1, self.G(sc + '/proj_1/kernel'), M, C, proj[0], T=T, kw=3)
-        self.colsum(dC1, self.G(sc + '/proj_1/bias'), M, proj[0])
         dPL = self.buf(sc + '/dpool', M, C)
         self.gemm_dx(dC1, self.P(sc + '/proj_1/kernel'), dPL, M, C, proj[0], T=T, kw=3)
         dB = self.buf(sc + '/dbank', M, C)
         self.bn_bwd(sc + '/conv_bank', b[sc + '/bank'], dPL, dB, M, C, T, 1, 1)
         self.gemm_dw(x, dB, self.G(sc + '/conv_bank/kernel'), M, cin, C, T=T, kw=K, bank=K, ldw=128)
-        self.colsum(dB, self.G(sc + '/conv_bank/bias'), M, C)
         self.gemm_dx(dB, self.P(sc + '/conv_bank/kernel'), dx, M, cin, C, T=T, kw=K, bank=K, ldw=128)
         lib.taco_add(dx, dHW0, dx, M * cin, 0, st)        # residual connection (modules.py:56)
         return dx
@@ -338,7 +350,7 @@ class Engine:
         dLIN = self.buf('dlin', Mp, self.L.ld_lin) if with_grad else None
         lib.taco_l1_loss(self.mel_outputs, self.nm, self.mel_targets, self.nm, dMEL, self.nm, self.loss_sums, Mp, self.nm, 0,
                          1.0 / (Mp * self.nm), 0.0, st)
-        lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin if with_grad else self.nf,
+        lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin,
                          self.loss_sums[2:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
 
     def loss_values(self):
@@ -357,6 +369,7 @@ class Engine:
         Me, Mp, Ms = N * Ti, N * To, N * S
         E = L.Et + L.Es
         self.grads.zero_()
+        self._side_active = self.overlap_wgrad
         dLIN, POST = b['dlin'], b['post_cbhg/out']
         # linear layer (tacotron.py:101)
         self.gemm_dw(POST, dLIN, self.G('linear/kernel'), Mp, 256, self.nf, ldw=L.ld_lin)
@@ -423,6 +436,9 @@ class Engine:
                                    self.G('embedding_id') if L.Es else None,
                                    self.gnorm2 if (self.tf_sparse_norm and self.world == 1) else None,
                                    N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
+        if self._side_active:
+            torch.cuda.current_stream().wait_stream(self.side_stream)      # join: all weight gradients are complete
+            self._side_active = False
 
     # ---- optimizer (models/tacotron.py:174-202) ---------------------------------------------------------------------------
     def optimizer_step(self):

@@ -68,16 +68,19 @@ def test_training_step_matches_golden(name):
 
 
 @pytest.mark.parametrize('cfg', [(4, 48, 120, 5, 0, 0), (5, 17, 35, 5, 0, 0), (1, 9, 12, 3, 0, 0), (3, 33, 16, 1, 7, 0),
-                                 (2, 40, 64, 2, 3, 0), (4, 24, 40, 5, 0, 1)])
+                                 (2, 40, 64, 2, 3, 0), (4, 24, 40, 5, 0, 1), (4, 48, 120, 5, 0, 2)])
 def test_training_step_matches_oracle(cfg):
     """ragged / odd batch sizes, r in {1,2,3,5}, single- and multi-speaker, perturbed BN/bias parameters.
-    Last config: one row is EOS + padding only.  Its constant (pad-embedding) input makes the conv-bank outputs
-    EXACTLY equal over time, i.e. max-pool ties at non-zero values; the HIP path routes ties to the first max
-    (TF CPU MaxPoolGrad), the float64 oracle's conv does not produce bit-equal rows, so its argmax is arbitrary
-    there: gradients of the bank are compared at a looser bar for that case only."""
+    Max-pool ties: padded text positions all carry embedding[0], so the conv-bank outputs are EXACTLY equal over
+    time there in the HIP path (ties at non-zero values, routed to the first max like TF CPU MaxPoolGrad), while
+    the float64 oracle's library conv does not produce bit-equal rows and its argmax in such a region is decided by
+    rounding noise.  Mode 0 therefore fills the padded text positions with random ids (tie-free: gradients held to
+    1e-3); mode 2 keeps the feeder's real zero padding and mode 1 adds an EOS-only row, both compared at a looser
+    gradient bar (forward outputs are unaffected and stay at 1e-3)."""
     from oracle import tacotron_np as onp, tacotron_torch as ot
-    N, Ti, To, r, idn, eos_only = cfg
-    gtol = 2e-2 if eos_only else TOL
+    N, Ti, To, r, idn, mode = cfg
+    eos_only = mode == 1
+    gtol = {0: TOL, 1: 2e-2, 2: 5e-3}[mode]
     P = onp.init_params(seed=21, r=r, id_num=idn)
     rng = np.random.RandomState(5)
     for k in P:                                   # move biases / BN affine away from their trivial initial values
@@ -86,6 +89,9 @@ def test_training_step_matches_oracle(cfg):
         if k.endswith('/gamma'):
             P[k] = P[k] * (1 + 0.2 * rng.standard_normal(P[k].shape))
     b = onp.synth_batch(N, Ti, To, r, seed=31, id_num=idn)
+    if mode == 0:
+        pad = b['inputs'] == 0
+        b['inputs'][pad] = np.random.RandomState(7).randint(2, 7352, size=int(pad.sum()))
     if eos_only:
         b['input_lengths'][0] = 1                 # shortest possible text: EOS only
         b['inputs'][0, :] = 0; b['inputs'][0, 0] = 1
