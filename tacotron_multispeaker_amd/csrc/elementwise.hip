@@ -351,32 +351,38 @@ __global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, 
 // sums[0] += sum|d| over all columns, sums[1] += sum|d| over columns < npri;
 // grad[row, c] = sign(out - tgt) * (w_all + (c < npri ? w_pri : 0)); padded columns [C, ldg) get 0.
 // =====================================================================================================
-__global__ void l1_loss_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt, float* __restrict__ grad, int ldg,
-                          double* __restrict__ sums, long rows, int C, int npri, float w_all, float w_pri) {
-    const int g4 = ldg >> 2;                        // float4 groups per (padded) row
-    const long total = rows * g4;
+__global__ __launch_bounds__(256) void l1_loss_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt,
+                                                float* __restrict__ grad, int ldg, double* __restrict__ sums, long rows, int C,
+                                                int npri, float w_all, float w_pri) {
+    // rows are strided over workgroups; inside a row consecutive lanes touch consecutive floats (rows of 1025 floats
+    // are not 16-byte aligned, so 4-byte lanes are the coalesced access)
     float s_all = 0.f, s_pri = 0.f;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long r = idx / g4;
-        const int c0 = (int)(idx - r * g4) * 4;
-        float g[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = c0 + k;
-            g[k] = 0.f;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* o = out + r * ldo;
+        const float* t = tgt + r * ldt;
+        float* g = grad ? grad + r * ldg : nullptr;
+        for (int c = threadIdx.x; c < ldg; c += 256) {
+            float gv = 0.f;
             if (c < C) {
-                const float d = out[r * ldo + c] - tgt[r * ldt + c];
+                const float d = o[c] - t[c];
                 const float a = fabsf(d);
                 s_all += a;
                 float w = w_all;
                 if (c < npri) { s_pri += a; w += w_pri; }
-                g[k] = d > 0.f ? w : (d < 0.f ? -w : 0.f);
+                gv = d > 0.f ? w : (d < 0.f ? -w : 0.f);
             }
+            if (g) g[c] = gv;
         }
-        if (grad) *reinterpret_cast<float4*>(grad + r * ldg + c0) = make_float4(g[0], g[1], g[2], g[3]);
     }
+    // one atomic pair per WORKGROUP (same-address atomics serialise: keep them to ~1k per launch)
     const double a = wave_sum_d((double)s_all), b = wave_sum_d((double)s_pri);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(sums, a); atomicAdd(sums + 1, b); }
+    __shared__ double red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
 }
 
 // =====================================================================================================
@@ -485,6 +491,6 @@ extern "C" int taco_add(const float* a, const float* b, float* y, long n, int ac
 extern "C" int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2,
                             long rows, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
     if (!out || !tgt || !sums2 || ldg < C || (ldg & 3)) return TACO_EINVAL;
-    hipLaunchKernelGGL(l1_loss_k, dim3(grid_for(rows * (ldg / 4))), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
+    hipLaunchKernelGGL(l1_loss_k, dim3((int)(rows < 1024 ? rows : 1024)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
     TACO_RETURN_LAST();
 }

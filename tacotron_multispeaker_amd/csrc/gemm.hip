@@ -12,6 +12,7 @@
 // 4 waves per workgroup in a 2x2 arrangement; tiles are staged through LDS with register double
 // buffering (global loads of tile s+1 are in flight while tile s is multiplied).
 #include "common.hpp"
+#include <stdlib.h>
 
 struct ConvGemm {
     const float* A; const float* B; float* C; const float* bias;
@@ -230,10 +231,19 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    // flattened (kw, j, kc) iteration state for the NEXT tile to load
+    // flattened (kw, j, kc) iteration state for the NEXT tile to load; blockIdx.z owns a contiguous share of the steps
     int l_kw = p.kw_lo, l_j = 0, l_kc = 0;
-    int nsteps = 0;
-    for (int kw = p.kw_lo; kw <= p.kw_hi; ++kw) nsteps += kw * ksteps;
+    int total = 0;
+    for (int kw = p.kw_lo; kw <= p.kw_hi; ++kw) total += kw * ksteps;
+    const int per = (total + p.splitk - 1) / p.splitk;
+    const int s_begin = blockIdx.z * per, s_end = min(total, s_begin + per);
+    if (s_begin >= s_end) return;
+    {   // advance the iteration state to s_begin
+        int skip = s_begin;
+        while (skip >= l_kw * ksteps) { skip -= l_kw * ksteps; ++l_kw; }
+        l_j = skip / ksteps; l_kc = skip - l_j * ksteps;
+    }
+    const int nsteps = s_end - s_begin;
 
     float4 ra[TA::NV], rb[TB::NV];
     auto gload = [&]() {
@@ -272,7 +282,20 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
         }
         __syncthreads();
     }
-    epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane);
+    if (p.splitk == 1) { epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane); return; }
+    const int i = lane & 31, h = lane >> 5;         // split-K: partial sums are atomically added into (zeroed) C
+#pragma unroll
+    for (int ni = 0; ni < BN / 64; ++ni) {
+        const int col = n0 + wn * (BN / 2) + ni * 32 + i;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.M) atomicAdd(p.C + (long)row * p.ldc + col, acc[mi][ni][r]);
+            }
+    }
 }
 
 // =====================================================================================================
@@ -356,6 +379,21 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(ConvGemm p) {
 }
 
 // ---- host-side dispatch --------------------------------------------------------------------------------
+// TACO_GEMM_TILE=128|64 forces the tile configuration (tuning aid); default: by tile count
+static int forced_tile() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TACO_GEMM_TILE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+// Measured on MI355X (scripts/dev_gemm.py): 64x64x32 tiles (4+ workgroups per CU, finer tail) match or beat
+// 128x128x16 on every C2 shape except very wide outputs (N >= 1024 with >= 1024 big tiles, e.g. the post-net bank).
+static bool use128(long tiles128, int N) {
+    const int f = forced_tile();
+    if (f == 128) return true;
+    if (f == 64) return false;
+    return tiles128 >= 1024 && N >= 1024;
+}
+
 static bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int check_common(const ConvGemm& p) {
@@ -378,7 +416,7 @@ extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* b
     if (int e = check_common(p)) return e;
     if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
     const long tiles128 = (long)cdiv(M, 128) * cdiv(p.N, 128);
-    if (tiles128 >= 192) {
+    if (use128(tiles128, p.N)) {
         dim3 g(cdiv(M, 128), cdiv(p.N, 128));
         hipLaunchKernelGGL((conv_gemm_nn<128, 128, 16>), g, dim3(256), 0, stream, p);
     } else {
@@ -398,11 +436,24 @@ extern "C" int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* d
     if (int e = check_common(p)) return e;
     if (M % T != 0 || kw < 1) return TACO_EINVAL;
     const long tiles128 = (long)cdiv(M, 128) * cdiv(p.N, 128);
-    if (tiles128 >= 192) {
+    if (forced_tile() == 128) {
         dim3 g(cdiv(M, 128), cdiv(p.N, 128));
         hipLaunchKernelGGL((conv_gemm_nt<128, 128, 16>), g, dim3(256), 0, stream, p);
     } else {
-        dim3 g(cdiv(M, 64), cdiv(p.N, 64));
+        // few output tiles but a long reduction (conv bank dX): split the taps over blockIdx.z, atomically accumulate
+        const long tiles = (long)cdiv(M, 64) * cdiv(p.N, 64);
+        int nsteps = 0;
+        for (int k = p.kw_lo; k <= p.kw_hi; ++k) nsteps += k * cdiv(p.K, 32);
+        int splitk = 1;
+        if (tiles < 256 && nsteps >= 64) {
+            splitk = (int)((768 + tiles - 1) / tiles);
+            if (splitk > nsteps / 16) splitk = nsteps / 16;
+            if (splitk < 1) splitk = 1;
+        }
+        p.splitk = splitk;
+        if (splitk > 1 && !accumulate)
+            if (hipMemset2DAsync(dX, (size_t)lddx * sizeof(float), 0, (size_t)Cin * sizeof(float), M, stream) != hipSuccess) return TACO_EINVAL;
+        dim3 g(cdiv(M, 64), cdiv(p.N, 64), splitk);
         hipLaunchKernelGGL((conv_gemm_nt<64, 64, 32>), g, dim3(256), 0, stream, p);
     }
     TACO_RETURN_LAST();

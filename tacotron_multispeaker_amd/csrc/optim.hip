@@ -18,7 +18,10 @@ __global__ void sumsq_k(const float* __restrict__ x, long n4, long n, double* __
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n4 * 4 + threadIdx.x]; s += v * v; }
     d += (double)s;
     d = wave_sum_d(d);
-    if ((threadIdx.x & 63) == 0) atomicAdd(acc, d);
+    __shared__ double red[4];               // one same-address atomic per workgroup (they serialise)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
 }
 
 struct AdamArgs {
@@ -72,7 +75,7 @@ __global__ void scale_k(float* __restrict__ x, long n4, float s) {
 extern "C" int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream) {
     if (!x || !acc || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return TACO_EINVAL;
     const long n4 = n / 4;
-    long g = (n4 + 255) / 256; if (g > 1024) g = 1024; if (g < 1) g = 1;
+    long g = (n4 + 255) / 256; if (g > 512) g = 512; if (g < 1) g = 1;
     hipLaunchKernelGGL(sumsq_k, dim3((int)g), dim3(256), 0, stream, x, n4, n, acc);
     TACO_RETURN_LAST();
 }
