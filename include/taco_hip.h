@@ -112,6 +112,10 @@ int taco_bn_ema(float* moving, const float* batch, int n, float momentum, hipStr
 int taco_step_inc(int* global_step, hipStream_t stream);
 int taco_scale(float* x, long n, float s, hipStream_t stream);
 
+/* diagnostic: micro-benchmark of the cluster all-gather (scripts/dev_xchg.py); not on the product path */
+int taco_xchg_bench(void* xchg, int* err, float* sink, int nclus, int cw, int len, int iters, int same_xcd, int sleep,
+                    int threads, hipStream_t stream);
+
 /* pointer-table slots of taco_attn_rnn_fwd / taco_attn_rnn_bwd (all fp32 device pointers) */
 enum TacoAttnPtr {
     TACO_AP_W1C = 0,   /* decoder_prenet dense_1 kernel rows 80:336 (context part)  [256,256] */

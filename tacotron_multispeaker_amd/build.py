@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libtaco_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DTACO_STAMP'] if os.environ.get('TACO_STAMP') else [])
 
 
 def sources():

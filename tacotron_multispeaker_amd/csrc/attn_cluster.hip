@@ -17,6 +17,17 @@
 #include "attn_cluster.hpp"
 
 #define CW 8                 // workgroups per cluster
+// Diagnostic build (-DTACO_STAMP): thread 0 of workgroup 0 accumulates s_memtime deltas per phase and writes them behind
+// the exchange region (never read by the kernel); the shipped build contains no stamp.
+#ifdef TACO_STAMP
+#define STAMP_DECL unsigned long long st_acc[16] = {0}; unsigned long long st_last = __builtin_readcyclecounter();
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; } } while (0)
+#define STAMP_OUT(ptr) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) (ptr)[i_] = st_acc[i_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_OUT(ptr)
+#endif
 #define AT 512               // threads per workgroup
 #define SPIN_LIMIT (1 << 22)
 #define PIDX(k) ((k) + ((k) >> 4) * 4)          // LDS vector layout: 4 pad floats after every 16 (bank spreading)
@@ -42,17 +53,15 @@ __device__ __forceinline__ void get_g(const u64* const (&ptr)[NG], unsigned epoc
     for (int i = 0; i < NG; ++i) out[i] = __uint_as_float((unsigned)x[i]);
 }
 
-__device__ __forceinline__ float fast_tanh_(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 // dot of this lane's K-part with the register weights, both rows; vec rows are PIDX-laid-out LDS vectors
 template <int KPER>
 __device__ __forceinline__ void dot2(const float* __restrict__ v0, const float* __restrict__ v1, int kbase,
                                      const float (&w)[KPER], float& a0, float& a1) {
 #pragma unroll
     for (int k4 = 0; k4 < KPER / 4; ++k4) {
+        // keep at most 4 LDS vectors in flight: hoisting every ds_read of a 32-deep part ahead of the FMAs costs
+        // 64 VGPRs and pushes the register-resident weights into scratch
+        if (k4 && (k4 & 1) == 0) asm volatile("" ::: "memory");
         const int k = kbase + k4 * 4;
         const float4 x0 = *reinterpret_cast<const float4*>(v0 + PIDX(k));
         const float4 x1 = *reinterpret_cast<const float4*>(v1 + PIDX(k));
@@ -63,16 +72,13 @@ __device__ __forceinline__ void dot2(const float* __restrict__ v0, const float* 
     }
 }
 template <int PARTS>
-__device__ __forceinline__ float lane_reduce(float v) {
-#pragma unroll
-    for (int o = 1; o < PARTS; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float lane_reduce(float v) { return group_sum<PARTS>(v); }
 
 // gather the 7 peers' slices (LEN values per row per workgroup) of a published vector into a PIDX LDS vector [2][..]
 template <int LEN>
 __device__ __forceinline__ void gather_vec(const u64* region, float* lds0, float* lds1, int w, unsigned epoch, int tid, int* err) {
     constexpr int TOT = 2 * (CW - 1) * LEN;
+    asm volatile("" : "+v"(tid));          // opaque: recompute the granule address per call, keep no pointer live
     if (tid < TOT) {
         const int row = tid / ((CW - 1) * LEN), rem = tid - row * (CW - 1) * LEN;
         const int peer = rem / LEN, jj = rem - peer * LEN;
@@ -108,8 +114,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     float* ep_l = q_l + 64;                       // [2*Ti] own partial scores
     float* a_l = ep_l + ((2 * Ti + 3) & ~3);      // [2*Ti] scores -> alignments
     float* cp_l = a_l + ((2 * Ti + 3) & ~3);      // [8][64] context partials
-    float* red_l = cp_l + 512;                    // [8] softmax scratch
-    float* K_l = red_l + 16;                      // [2][Ti][32]
+    float* red_l = cp_l + 512;                    // [32] attention_v slice
+    float* K_l = red_l + 32;                      // [2][Ti][32]
     float* M_l = K_l + 2 * Ti * 32;               // [2][Ti][32]
     for (int i = tid; i < 2 * PLEN(256) * 4 + 2 * PLEN(128); i += AT) smem[i] = 0.0f;    // ctx,p1,p2,h,rh = 0
     for (int i = tid; i < 2 * Ti * 8; i += AT) {          // float4 granularity: (row, t, c4)
@@ -140,25 +146,29 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) wqr[k] = p.wq[(long)(pA * 16 + k) * 256 + 32 * w + cA];
     const float b2v = p.b2[16 * w + cB], bgv = p.bg[gc], bcv = p.bg[512 + 32 * w + cA];
-    // attention_v for this lane's 16 score dims (scores mapping: pair = tid>>1, half = tid&1)
-    float vv[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) vv[k] = p.v[32 * w + (tid & 1) * 16 + k];
+    // attention_v slice of this workgroup's 32 score dims lives in LDS (red_l[0:32])
+    if (tid < 32) red_l[tid] = p.v[32 * w + tid];
 
     // exchange regions of this cluster: CTX, P1 [2][256]; P2 [2][128]; RH, H [2][256]; E [8][2*Ti]
     const long per_clu = 2 * 256 * 4 + 2 * 128 + (long)CW * 2 * Ti;
     u64* X = p.xchg + (long)cl * per_clu;
     u64 *xCTX = X, *xP1 = X + 512, *xP2 = X + 1024, *xRH = X + 1280, *xH = X + 1792, *xE = X + 2304;
+    float fnx0 = 0.f, fnx1 = 0.f;
+    if (pA == 0) { fnx0 = p.f1[(unsigned)(rw[0] * S) * 256u + 32 * w + cA]; fnx1 = p.f1[(unsigned)(rw[1] * S) * 256u + 32 * w + cA]; }
     __syncthreads();
+    STAMP_DECL
 
     for (int s = 0; s < S; ++s) {
         const unsigned epoch = (unsigned)s + 1;
-        const long so0 = rw[0] * S + s, so1 = rw[1] * S + s;       // row offsets into [N,S,*] tensors
+        STAMP(0);
+        unsigned so0 = (unsigned)(rw[0] * S + s), so1 = (unsigned)(rw[1] * S + s);   // row offsets into [N,S,*] tensors
+        asm volatile("" : "+v"(so0), "+v"(so1));      // opaque: addresses are formed at the point of use (see above)
         // ================= A: prenet dense_1 (context part; frame part + bias hoisted into f1) =================
         {
             const int j = 32 * w + cA;
-            float f0 = 0.f, f1v = 0.f;
-            if (pA == 0) { f0 = p.f1[so0 * 256 + j]; f1v = p.f1[so1 * 256 + j]; }
+            // frame part of dense_1 for this step was fetched one step ahead (HBM latency off the critical path)
+            const float f0 = fnx0, f1v = fnx1;
+            if (pA == 0 && s + 1 < S) { fnx0 = p.f1[(so0 + 1u) * 256u + j]; fnx1 = p.f1[(so1 + 1u) * 256u + j]; }
             float a0 = 0.f, a1 = 0.f;
             dot2<16>(ctx_l, ctx_l + PLEN(256), pA * 16, w1, a0, a1);
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
@@ -169,9 +179,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 if (ok[0]) p.p1[so0 * 256 + j] = a0;
                 if (ok[1]) p.p1[so1 * 256 + j] = a1;
             }
+            STAMP(1);
             gather_vec<32>(xP1, p1_l, p1_l + PLEN(256), w, epoch, tid, p.err);
         }
         __syncthreads();
+        STAMP(2);
         // ================= B: prenet dense_2 =================
         {
             const int j = 16 * w + cB;
@@ -185,9 +197,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 if (ok[0]) p.p2[so0 * 128 + j] = a0;
                 if (ok[1]) p.p2[so1 * 128 + j] = a1;
             }
+            STAMP(3);
             gather_vec<16>(xP2, p2_l, p2_l + PLEN(128), w, epoch, tid, p.err);
         }
         __syncthreads();
+        STAMP(4);
         // ================= C: GRU gates =================
         {
             const int j = 32 * w + (cC & 31);
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             dot2<32>(h_l, h_l + PLEN(256), pC * 32, wgh, a0, a1);
             a0 = lane_reduce<8>(a0); a1 = lane_reduce<8>(a1);
             if (pC == 0) {
-                const float g0 = sigmoidf_(a0 + bgv), g1 = sigmoidf_(a1 + bgv);
+                const float g0 = fast_sigmoid(a0 + bgv), g1 = fast_sigmoid(a1 + bgv);
                 if (cC < 32) {
                     const float q0 = g0 * h_l[PIDX(j)], q1 = g1 * h_l[PLEN(256) + PIDX(j)];
                     rh_l[PIDX(j)] = q0; rh_l[PLEN(256) + PIDX(j)] = q1;
@@ -209,9 +223,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                     if (ok[1]) p.u[so1 * 256 + j] = g1;
                 }
             }
+            STAMP(5);
             gather_vec<32>(xRH, rh_l, rh_l + PLEN(256), w, epoch, tid, p.err);
         }
         __syncthreads();
+        STAMP(6);
         // ================= D: candidate + new state =================
         {
             const int j = 32 * w + cA;
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             dot2<16>(rh_l, rh_l + PLEN(256), pA * 16, wch, a0, a1);
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
             if (pA == 0) {
-                const float c0 = tanhf_(a0 + bcv), c1 = tanhf_(a1 + bcv);
+                const float c0 = fast_tanh(a0 + bcv), c1 = fast_tanh(a1 + bcv);
                 const float u0 = u_l[cA], u1 = u_l[32 + cA];
                 const float hn0 = u0 * h_l[PIDX(j)] + (1.f - u0) * c0;
                 const float hn1 = u1 * h_l[PLEN(256) + PIDX(j)] + (1.f - u1) * c1;
@@ -229,9 +245,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 if (ok[0]) { p.c[so0 * 256 + j] = c0; p.hc[so0 * 512 + j] = hn0; }
                 if (ok[1]) { p.c[so1 * 256 + j] = c1; p.hc[so1 * 512 + j] = hn1; }
             }
+            STAMP(7);
             gather_vec<32>(xH, h_l, h_l + PLEN(256), w, epoch, tid, p.err);
         }
         __syncthreads();
+        STAMP(8);
         // ================= E: query slice =================
         {
             float a0 = 0.f, a1 = 0.f;
@@ -244,24 +262,28 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             }
         }
         __syncthreads();
+        STAMP(9);
         // ================= F: partial scores over this workgroup's 32 dims, all t =================
         for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
             const int half = tid & 1;
             const int row = i >= Ti;
             const float* kp = K_l + i * 32 + half * 16;
             const float* qp = q_l + row * 32 + half * 16;
+            const float* vp = red_l + half * 16;
             float e = 0.f;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
                 const float4 kv = *reinterpret_cast<const float4*>(kp + d4 * 4);
                 const float4 qv = *reinterpret_cast<const float4*>(qp + d4 * 4);
-                e = fmaf(vv[d4 * 4], fast_tanh_(kv.x + qv.x), e); e = fmaf(vv[d4 * 4 + 1], fast_tanh_(kv.y + qv.y), e);
-                e = fmaf(vv[d4 * 4 + 2], fast_tanh_(kv.z + qv.z), e); e = fmaf(vv[d4 * 4 + 3], fast_tanh_(kv.w + qv.w), e);
+                const float4 vv = *reinterpret_cast<const float4*>(vp + d4 * 4);
+                e = fmaf(vv.x, fast_tanh(kv.x + qv.x), e); e = fmaf(vv.y, fast_tanh(kv.y + qv.y), e);
+                e = fmaf(vv.z, fast_tanh(kv.z + qv.z), e); e = fmaf(vv.w, fast_tanh(kv.w + qv.w), e);
             }
-            e += __shfl_xor(e, 1, 64);
+            e = dpp_add<0xB1>(e);
             if (half == 0) { ep_l[i] = e; put_g(xE + (long)w * 2 * Ti + i, epoch, e); }
         }
         __syncthreads();
+        STAMP(10);
         // gather + reduce the 8 partials of every (row,t) in workgroup order (bit-identical in all members)
         for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
             const int half = tid & 1;
@@ -277,10 +299,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? ep_l[i] : val[k];
-            const float other = __shfl_xor(sum, 1, 64);
-            if (half == 0) a_l[i] = sum + other;
+            const float tot2 = dpp_add<0xB1>(sum);
+            if (half == 0) a_l[i] = tot2;
         }
         __syncthreads();
+        STAMP(11);
         // ================= G: softmax over all Ti (wave 0 -> row 0, wave 1 -> row 1) =================
         if (tid < 128) {
             const int row = tid >> 6, lane = tid & 63;
@@ -289,16 +312,17 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             for (int t = lane; t < Ti; t += 64) mx = fmaxf(mx, ar[t]);
             mx = wave_max(mx);
             float sm = 0.f;
-            for (int t = lane; t < Ti; t += 64) { const float x = expf(ar[t] - mx); ar[t] = x; sm += x; }
+            for (int t = lane; t < Ti; t += 64) { const float x = __builtin_amdgcn_exp2f((ar[t] - mx) * 1.4426950408889634f); ar[t] = x; sm += x; }
             sm = wave_sum(sm);
             const float inv = 1.0f / sm;
             for (int t = lane; t < Ti; t += 64) ar[t] *= inv;
         }
         __syncthreads();
+        STAMP(12);
         // alignments to HBM: member w writes t = w, w+8, ...
         for (int i = tid; i < 2 * Ti; i += AT) {
             const int row = i >= Ti, t = i - row * Ti;
-            if ((t & 7) == w && ok[row]) p.align[(rw[row] * S + s) * Ti + t] = a_l[i];
+            if ((t & 7) == w && ok[row]) p.align[(row ? so1 : so0) * (unsigned)Ti + t] = a_l[i];
         }
         // ================= H: context slice: ctx[row][d] = sum_t a[t] * mem[t][d] =================
         {
@@ -317,19 +341,22 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             for (int tp = 0; tp < 8; ++tp) cx += cp_l[tp * 64 + tid];
             ctx_l[row * PLEN(256) + PIDX(j)] = cx;
             put_g(xCTX + row * 256 + j, epoch, cx);
-            if (ok[row]) p.hc[(rw[row] * S + s) * 512 + 256 + j] = cx;
+            if (ok[row]) p.hc[(row ? so1 : so0) * 512u + 256u + j] = cx;
         }
+        STAMP(13);
         gather_vec<32>(xCTX, ctx_l, ctx_l + PLEN(256), w, epoch, tid, p.err);
         __syncthreads();
+        STAMP(14);
     }
+    STAMP_OUT(p.xchg + (long)nclus * per_clu);
 }
 
 extern "C" int taco_attn_cluster_xchg_slots(int N, int Ti) {
-    return ((N + 1) / 2) * (2 * 256 * 4 + 2 * 128 + CW * 2 * Ti);
+    return ((N + 1) / 2) * (2 * 256 * 4 + 2 * 128 + CW * 2 * Ti) + 16;     // + 16 diagnostic stamp slots
 }
 
 static size_t attn_cluster_smem(int Ti) {
-    size_t f = 2 * PLEN(256) * 4 + 2 * PLEN(128) + 64 + 64 + 2 * ((2 * Ti + 3) & ~3) + 512 + 16 + (size_t)4 * Ti * 32;
+    size_t f = 2 * PLEN(256) * 4 + 2 * PLEN(128) + 64 + 64 + 2 * ((2 * Ti + 3) & ~3) + 512 + 32 + (size_t)4 * Ti * 32;
     return f * sizeof(float);
 }
 
@@ -348,7 +375,7 @@ int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
             return TACO_EINVAL;
         attr_set = true;
     }
-    if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    if (hipMemsetAsync(p.xchg, 0, (size_t)(taco_attn_cluster_xchg_slots(p.N, p.Ti) - 16) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
     hipLaunchKernelGGL(attn_cluster_fwd_k, dim3(CW * ((p.N + 1) / 2)), dim3(AT), smem, st, p);
     TACO_RETURN_LAST();
 }
@@ -370,6 +397,7 @@ __device__ __forceinline__ void gather2(const u64* regA, const u64* regB, float*
                                         int w, unsigned epoch, int tid, int* err) {
     // two published vectors of LEN values per row per workgroup gathered with ONE poll round trip (2 granules/thread)
     constexpr int TOT = 2 * (CW - 1) * LEN;
+    asm volatile("" : "+v"(tid));          // opaque: recompute the granule address per call, keep no pointer live
     if (tid < TOT) {
         const int row = tid / ((CW - 1) * LEN), rem = tid - row * (CW - 1) * LEN;
         const int peer = rem / LEN, jj = rem - peer * LEN;
@@ -387,6 +415,7 @@ template <int LEN>
 __device__ __forceinline__ void gather_off(const u64* region, float* lds0, float* lds1, int off, int w, unsigned epoch,
                                            int tid, int* err) {
     constexpr int TOT = 2 * (CW - 1) * LEN;
+    asm volatile("" : "+v"(tid));          // opaque: recompute the granule address per call, keep no pointer live
     if (tid < TOT) {
         const int row = tid / ((CW - 1) * LEN), rem = tid - row * (CW - 1) * LEN;
         const int peer = rem / LEN, jj = rem - peer * LEN;
@@ -457,26 +486,41 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
 
     float dhc0 = 0.f, dhc1 = 0.f;      // dh carry   (owner lanes: pA == 0, index jA)
     float dcc0 = 0.f, dcc1 = 0.f;      // dctx carry (owner lanes: pA == 0, index jA)
+    // one-step-ahead prefetch registers, primed for s = S-1
+    float pf_a = 0.f, pf_q = 0.f, pf_r[2] = {0, 0}, pf_u[2] = {0, 0}, pf_c[2] = {0, 0}, pf_hp[2] = {0, 0}, pf_dhe[2] = {0, 0},
+          pf_dce[2] = {0, 0}, pf_p1[2] = {0, 0}, pf_p2[2] = {0, 0};
+    {
+        const unsigned sl[2] = {(unsigned)(rw[0] * S + S - 1), (unsigned)(rw[1] * S + S - 1)};
+        if (2 * Ti <= AT && tid < 2 * Ti) { const int row = tid >= Ti; pf_a = p.align[sl[row] * (unsigned)Ti + (tid - row * Ti)]; }
+        if (tid < 64) pf_q = p.q[sl[tid >> 5] * 256u + 32 * w + (tid & 31)];
+        if (pA == 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                pf_r[b] = p.r[sl[b] * 256u + jA]; pf_u[b] = p.u[sl[b] * 256u + jA]; pf_c[b] = p.c[sl[b] * 256u + jA];
+                pf_hp[b] = S > 1 ? p.hc[(sl[b] - 1u) * 512u + jA] : 0.f;
+                pf_dhe[b] = p.dhc[sl[b] * 512u + jA]; pf_dce[b] = p.dhc[sl[b] * 512u + 256u + jA];
+                pf_p1[b] = p.p1[sl[b] * 256u + jA];
+            }
+        }
+        if (pB == 0) { pf_p2[0] = p.p2[sl[0] * 128u + jB]; pf_p2[1] = p.p2[sl[1] * 128u + jB]; }
+    }
     __syncthreads();
 
     for (int s = S - 1; s >= 0; --s) {
         const unsigned epoch = (unsigned)(S - s);
-        const long so[2] = {rw[0] * S + s, rw[1] * S + s};
-        // ---- prefetch this step's saved activations / external gradients
-        for (int i = tid; i < 2 * Ti; i += AT) { const int row = i >= Ti; a_l[i] = p.align[so[row] * Ti + (i - row * Ti)]; }
-        if (tid < 64) q_l[tid] = p.q[so[tid >> 5] * 256 + 32 * w + (tid & 31)];
-        float r_[2] = {0, 0}, u_[2] = {0, 0}, c_[2] = {0, 0}, hp_[2] = {0, 0}, dhe[2] = {0, 0}, dce[2] = {0, 0}, p1v[2] = {0, 0};
-        float p2v[2] = {0, 0};
-        if (pA == 0) {
+        unsigned so[2] = {(unsigned)(rw[0] * S + s), (unsigned)(rw[1] * S + s)};
+        asm volatile("" : "+v"(so[0]), "+v"(so[1]));   // opaque per-step offsets: no precomputed 64-bit addresses kept live
+        // ---- this step's saved activations / external gradients were fetched ONE STEP AHEAD (registers), so their HBM
+        //      latency is off the critical path; now issue the loads for step s-1
+        if (2 * Ti <= AT) { if (tid < 2 * Ti) a_l[tid] = pf_a; }
+        else for (int i = tid; i < 2 * Ti; i += AT) { const int row = i >= Ti; a_l[i] = p.align[so[row] * (unsigned)Ti + (i - row * Ti)]; }
+        if (tid < 64) q_l[tid] = pf_q;
+        float r_[2], u_[2], c_[2], hp_[2], dhe[2], dce[2], p1v[2], p2v[2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                r_[b] = p.r[so[b] * 256 + jA]; u_[b] = p.u[so[b] * 256 + jA]; c_[b] = p.c[so[b] * 256 + jA];
-                hp_[b] = s > 0 ? p.hc[(so[b] - 1) * 512 + jA] : 0.f;
-                dhe[b] = p.dhc[so[b] * 512 + jA]; dce[b] = p.dhc[so[b] * 512 + 256 + jA];
-                p1v[b] = p.p1[so[b] * 256 + jA];
-            }
+        for (int b = 0; b < 2; ++b) {
+            r_[b] = pf_r[b]; u_[b] = pf_u[b]; c_[b] = pf_c[b]; hp_[b] = pf_hp[b]; dhe[b] = pf_dhe[b]; dce[b] = pf_dce[b];
+            p1v[b] = pf_p1[b]; p2v[b] = pf_p2[b];
         }
-        if (pB == 0) { p2v[0] = p.p2[so[0] * 128 + jB]; p2v[1] = p.p2[so[1] * 128 + jB]; }
         // ================= X1: total dctx (own slice), da partials =================
         if (pA == 0) {
             const float d0 = dce[0] + dcc0, d1 = dce[1] + dcc1;
@@ -496,7 +540,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 const float4 gv = *reinterpret_cast<const float4*>(gp + d4 * 4);
                 e = fmaf(mv.x, gv.x, e); e = fmaf(mv.y, gv.y, e); e = fmaf(mv.z, gv.z, e); e = fmaf(mv.w, gv.w, e);
             }
-            e += __shfl_xor(e, 1, 64);
+            e = dpp_add<0xB1>(e);
             if (half == 0) { ep_l[i] = e; put_g(xDA + (long)w * 2 * Ti + i, epoch, e); }
         }
         __syncthreads();
@@ -514,8 +558,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? ep_l[i] : val[k];
-            const float other = __shfl_xor(sum, 1, 64);
-            if (half == 0) de_l[i] = sum + other;                 // da[row][t]
+            const float tot2 = dpp_add<0xB1>(sum);
+            if (half == 0) de_l[i] = tot2;                        // da[row][t]
         }
         __syncthreads();
         // ================= X2: softmax backward: de = a * (da - sum a*da) =================
@@ -540,7 +584,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             const float* kr = K_l + row * Ti * 32 + d;
             const float qd = q_l[row * 32 + d];
             float acc = 0.f;
-            for (int t = tp; t < Ti; t += 8) { const float th = fast_tanh_(kr[t * 32] + qd); acc = fmaf(er[t], 1.f - th * th, acc); }
+            for (int t = tp; t < Ti; t += 8) { const float th = fast_tanh(kr[t * 32] + qd); acc = fmaf(er[t], 1.f - th * th, acc); }
             cp_l[tp * 64 + row * 32 + d] = acc * vd;
         }
         __syncthreads();
@@ -599,6 +643,20 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             gather2<32>(xDGR, xDGU, dxp_l, dxp_l + PLEN(768), 0, 256, w, epoch, tid, p.err);
         }
         __syncthreads();
+        // ---- issue the loads for step s-1 (consumed at the top of the next iteration)
+        if (s > 0) {
+            const unsigned sn[2] = {so[0] - 1u, so[1] - 1u};
+            if (2 * Ti <= AT && tid < 2 * Ti) { const int row = tid >= Ti; pf_a = p.align[sn[row] * (unsigned)Ti + (tid - row * Ti)]; }
+            if (tid < 64) pf_q = p.q[sn[tid >> 5] * 256u + 32 * w + (tid & 31)];
+            if (pA == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    pf_r[b] = p.r[sn[b] * 256u + jA]; pf_u[b] = p.u[sn[b] * 256u + jA]; pf_c[b] = p.c[sn[b] * 256u + jA];
+                    pf_hp[b] = s > 1 ? p.hc[(sn[b] - 1u) * 512u + jA] : 0.f;
+                    pf_dhe[b] = p.dhc[sn[b] * 512u + jA]; pf_dce[b] = p.dhc[sn[b] * 512u + 256u + jA];
+                                    }
+            }
+        }
         // ================= X6: dh carry = dhp + dg . Whg^T ;  dp2pre = (dxp . Wx^T) * (p2 > 0) =================
         {
             float a0 = 0.f, a1 = 0.f;
@@ -633,6 +691,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             gather_vec<32>(xDP1, dp1_l, dp1_l + PLEN(256), w, epoch, tid, p.err);
         }
         __syncthreads();
+        if (s > 0) {
+            if (pA == 0) { pf_p1[0] = p.p1[(so[0] - 1u) * 256u + jA]; pf_p1[1] = p.p1[(so[1] - 1u) * 256u + jA]; }
+            if (pB == 0) { pf_p2[0] = p.p2[(so[0] - 1u) * 128u + jB]; pf_p2[1] = p.p2[(so[1] - 1u) * 128u + jB]; }
+        }
         // ================= X8: dctx carry (gradient wrt ctx_{s-1}) = dp1pre . W1c^T =================
         {
             float a0 = 0.f, a1 = 0.f;
@@ -664,7 +726,7 @@ __global__ __launch_bounds__(256) void attn_hoisted_bwd_k(const float* __restric
 #pragma unroll 4
     for (int s = 0; s < S; ++s) {
         const float a = ap[(long)s * Ti], e = ep[(long)s * Ti];
-        const float th = fast_tanh_(kd + qp[(long)s * 256]);
+        const float th = fast_tanh(kd + qp[(long)s * 256]);
         am = fmaf(a, cp[(long)s * 256], am);
         ak = fmaf(e, 1.f - th * th, ak);
         av = fmaf(e, th, av);

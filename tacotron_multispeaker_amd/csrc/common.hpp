@@ -34,6 +34,32 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
+// ---- latency-critical variants for the persistent recurrence kernels ----------------------------------------------
+// v_exp_f32 / v_rcp_f32 based (1 ulp each): abs error ~1e-7, ~6 instructions instead of ~40
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+// Sum over groups of PARTS adjacent lanes (PARTS = 2,4,8,16,32; groups aligned) with DPP cross-lane adds: one VALU
+// instruction per level instead of a ds_bpermute round trip through the LDS crossbar (~100+ cycles each).
+// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int PARTS>
+__device__ __forceinline__ float group_sum(float v) {
+    if (PARTS >= 2) v = dpp_add<0xB1>(v);
+    if (PARTS >= 4) v = dpp_add<0x4E>(v);
+    if (PARTS >= 8) v = dpp_add<0x141>(v);
+    if (PARTS >= 16) v = dpp_add<0x140>(v);
+    if (PARTS >= 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // lane ^ 16
+    return v;
+}
+
 // 64-lane wavefront reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

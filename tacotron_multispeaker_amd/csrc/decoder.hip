@@ -35,12 +35,6 @@ struct Skinny {
     float* o[4]; int ldo[4];
 };
 
-__device__ __forceinline__ float fast_tanh(float x) {
-    // 1 - 2/(1+e^{2x}) through v_exp_f32 / v_rcp_f32; abs error ~1e-7
-    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 // One wave's share of a segment: chunks of 16 k (4 per lane-quarter); loads of up to 4 chunks are issued
 // back-to-back before the first MFMA so a wave pays ~one L2 round trip per 64 k instead of one per 16 k.
 template <bool BT>

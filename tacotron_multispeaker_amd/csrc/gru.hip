@@ -92,9 +92,9 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
                 a = fmaf(v.z, wg[k4 * 4 + 2], a); a = fmaf(v.w, wg[k4 * 4 + 3], a);
             }
         }
-        a += __shfl_xor(a, 1, 64);
+        a = group_sum<2>(a);
         if (kh == 0) {
-            const float g = sigmoidf_(a + ag);
+            const float g = fast_sigmoid(a + ag);
             ruc[(long)t * 3 * H + gcol] = g;
             if (gcol < H) rh_l[LIDX(gcol)] = g * h_l[LIDX(gcol)];
             else u_l[gcol - H] = g;
@@ -111,10 +111,9 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
                 b = fmaf(v.z, wc[k4 * 4 + 2], b); b = fmaf(v.w, wc[k4 * 4 + 3], b);
             }
         }
-        b += __shfl_xor(b, 1, 64);
-        b += __shfl_xor(b, 2, 64);
+        b = group_sum<4>(b);
         if (kq == 0) {
-            const float c = tanhf_(b + ac);
+            const float c = fast_tanh(b + ac);
             const float hprev = h_l[LIDX(ccol)];
             const float u = u_l[ccol];
             const float hn = u * hprev + (1.0f - u) * c;
@@ -190,8 +189,7 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
                 drh = fmaf(v.z, wcT[q * 4 + 2], drh); drh = fmaf(v.w, wcT[q * 4 + 3], drh);
             }
         }
-        drh += __shfl_xor(drh, 1, 64);
-        drh += __shfl_xor(drh, 2, 64);
+        drh = group_sum<4>(drh);
         if (owner) {
             dh_new += drh * r;
             const float dgr = drh * hprev * r * (1.0f - r);
@@ -215,8 +213,7 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
                 e = fmaf(v.z, wgT[q * 4 + 2], e); e = fmaf(v.w, wgT[q * 4 + 3], e);
             }
         }
-        e += __shfl_xor(e, 1, 64);
-        e += __shfl_xor(e, 2, 64);
+        e = group_sum<4>(e);
         dh = dh_new + e;
     }
 }

@@ -113,11 +113,11 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_fwd_k(Gru256 p) {
             a0 = fmaf(v0.z, wg[k4 * 4 + 2], a0); a1 = fmaf(v1.z, wg[k4 * 4 + 2], a1);
             a0 = fmaf(v0.w, wg[k4 * 4 + 3], a0); a1 = fmaf(v1.w, wg[k4 * 4 + 3], a1);
         }
-        a0 += __shfl_xor(a0, 1, 64);
-        a1 += __shfl_xor(a1, 1, 64);
+        a0 = group_sum<2>(a0);
+        a1 = group_sum<2>(a1);
         if (kh == 0) {
-            const float g0 = sigmoidf_(a0 + xg0);
-            const float g1 = sigmoidf_(a1 + xg1);
+            const float g0 = fast_sigmoid(a0 + xg0);
+            const float g1 = fast_sigmoid(a1 + xg1);
             if (gcol < 64) {
                 const float q0 = g0 * h_lds[0][hidx(j_own)], q1 = g1 * h_lds[1][hidx(j_own)];
                 rh_lds[0][hidx(j_own)] = q0; rh_lds[1][hidx(j_own)] = q1;
@@ -155,11 +155,10 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_fwd_k(Gru256 p) {
             c0 = fmaf(v0.z, wc[k4 * 4 + 2], c0); c1 = fmaf(v1.z, wc[k4 * 4 + 2], c1);
             c0 = fmaf(v0.w, wc[k4 * 4 + 3], c0); c1 = fmaf(v1.w, wc[k4 * 4 + 3], c1);
         }
-        c0 += __shfl_xor(c0, 1, 64); c1 += __shfl_xor(c1, 1, 64);
-        c0 += __shfl_xor(c0, 2, 64); c1 += __shfl_xor(c1, 2, 64);
+        c0 = group_sum<4>(c0); c1 = group_sum<4>(c1);
         if (kq == 0) {
-            const float cc0 = tanhf_(c0 + xc0);
-            const float cc1 = tanhf_(c1 + xc1);
+            const float cc0 = fast_tanh(c0 + xc0);
+            const float cc1 = fast_tanh(c1 + xc1);
             const float u0 = u_lds[0][ccol], u1 = u_lds[1][ccol];
             const float hn0 = u0 * h_lds[0][hidx(jc)] + (1.0f - u0) * cc0;
             const float hn1 = u1 * h_lds[1][hidx(jc)] + (1.0f - u1) * cc1;
@@ -263,8 +262,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_bwd_k(Gru256 p) {
                 d0 = fmaf(v0.w, wcT[j4 * 4 + 3], d0); d1 = fmaf(v1.w, wcT[j4 * 4 + 3], d1);
             }
         }
-        d0 += __shfl_xor(d0, 1, 64); d1 += __shfl_xor(d1, 1, 64);
-        d0 += __shfl_xor(d0, 2, 64); d1 += __shfl_xor(d1, 2, 64);
+        d0 = group_sum<4>(d0); d1 = group_sum<4>(d1);
         float dhp0 = 0.0f, dhp1 = 0.0f;         // partial dh_{s-1}[k_own] (valid in lanes jq == 0)
         if (jq == 0) {
             const float drh[2] = {d0, d1};
@@ -319,8 +317,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_bwd_k(Gru256 p) {
                 e0 = fmaf(v0.w, wgT[j4 * 4 + 3], e0); e1 = fmaf(v1.w, wgT[j4 * 4 + 3], e1);
             }
         }
-        e0 += __shfl_xor(e0, 1, 64); e1 += __shfl_xor(e1, 1, 64);
-        e0 += __shfl_xor(e0, 2, 64); e1 += __shfl_xor(e1, 2, 64);
+        e0 = group_sum<4>(e0); e1 = group_sum<4>(e1);
         // hand dh_{s-1} to the elementwise owner threads through LDS (own_lds slot 2 is free again)
         if (jq == 0) { own_lds[0][kk][2] = dhp0 + e0; own_lds[1][kk][2] = dhp1 + e1; }
         __syncthreads();
