@@ -158,6 +158,20 @@ def main():
     for i in range(a.warmup):
         step(i)
 
+    # HIP-graph replay vs eager launches: keep whichever is faster on this box (the multi-stream graph is not always
+    # the winner once the step is GPU-bound); decided on 3 untimed steps each, identically on every rank
+    if use_graph and world == 1:
+        def probe(g):
+            nonlocal use_graph
+            use_graph = g
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for i in range(3):
+                step(i)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+        tg, te = probe(True), probe(False)
+        use_graph = tg <= te
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
