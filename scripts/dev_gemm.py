@@ -12,6 +12,7 @@ def timeit(fn, n=10):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 shapes = [  # name, M, T, Cin, Cout, kw, bank
+    ('dense 16k', 16384, 16384, 2048, 2048, 1, 0), ('dense 8k', 8192, 8192, 4096, 4096, 1, 0),
     ('post proj_1', 20480, 640, 1024, 256, 3, 0), ('post bank', 20480, 640, 80, 1024, 8, 8), ('enc bank', 4096, 128, 128, 2048, 16, 16),
     ('enc proj_1', 4096, 128, 2048, 128, 3, 0), ('linear', 20480, 20480, 256, 1025, 1, 0), ('post xp', 20480, 20480, 128, 768, 1, 0),
     ('post hw', 20480, 20480, 128, 256, 1, 0), ('post proj_2', 20480, 640, 256, 80, 3, 0), ('dec xp', 4096, 4096, 256, 768, 1, 0)]

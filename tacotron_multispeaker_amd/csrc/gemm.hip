@@ -72,6 +72,19 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
     }
 }
 
+// ---- XCD-aware tile order (speed only) -------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  Give every XCD a contiguous run of "virtual"
+// tile ids ordered column-tile-fastest, so the column tiles that re-read the same A rows (and the taps of one row tile)
+// hit in ONE L2 instead of fetching the rows once per XCD (rocprofv3 FETCH_SIZE of the post-net proj_1 conv: 424 MB for
+// 87 MB of operands before this remap).  Bijective for any grid size.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int total = nbx * nby, lin = blockIdx.y * nbx + blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bx = v / nby; by = v - bx * nby;
+}
+
 // ---- tile loaders (global -> registers, registers -> LDS) --------------------------------------------
 // k-contiguous tile [ROWS][BK]: thread owns float4 #(tid + v*256); BK/4 float4 per row
 template <int ROWS, int BK>
@@ -140,8 +153,10 @@ __global__ __launch_bounds__(256) void conv_gemm_nn(ConvGemm p) {
     using TB = KS<BN, BK>;
     __shared__ __attribute__((aligned(16))) float smem[2][BM * (BK + 4) + BK * BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM;
-    const int by = p.bank ? (gridDim.y - 1 - blockIdx.y) : blockIdx.y;  // bank: widest convs first
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.bank) by = gridDim.y - 1 - blockIdx.y;                         // bank: widest convs first
+    else xcd_tile(bx, by);
+    const int m0 = bx * BM;
     const int n0 = by * BN;
 
     int kw = p.kw_lo, ldb = p.ldb, nloc0 = n0, nlim = p.N;
@@ -216,7 +231,9 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
     using TB = KC<BN, BK>;
     __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * (BK + 4)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
     const int ksteps = (p.K + BK - 1) / BK;
 
     int tpos[TA::NV];
