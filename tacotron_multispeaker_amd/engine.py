@@ -56,6 +56,7 @@ class Engine:
         self._dpos = 0
         self.side_stream = torch.cuda.Stream(device=self.dev)
         self._side_active = False
+        self._deferred = []
         self.overlap_wgrad = True
         self.world = 1
         self.load_named(named_params if named_params is not None else init_named(L, seed))
@@ -123,11 +124,21 @@ class Engine:
     def _side(self, fn):
         if not self._side_active:
             return fn()
+        self._deferred.append(fn)          # released by flush_side() when a recurrence kernel has just been launched
+
+    def flush_side(self):
+        """Enqueue the pending weight-gradient work on the side stream.  Called right AFTER a persistent recurrence
+        kernel was launched on the main stream: that kernel occupies <= 128 CUs for ~1 ms, the GEMMs fill the rest;
+        between recurrences the critical-path GEMMs keep the machine to themselves."""
+        if not self._deferred:
+            return
         ev = torch.cuda.Event()
         ev.record()
         self.side_stream.wait_event(ev)
         with torch.cuda.stream(self.side_stream):
-            fn()
+            for fn in self._deferred:
+                fn()
+        self._deferred = []
 
     def gemm_dw(self, X, dY, dW, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, lddy=None, ldw=None):
         self._side(lambda: lib.taco_conv_gemm_bwd_weight(X, dY, dW, M, T or M, Cin, Cout, kw, bank,
@@ -216,6 +227,7 @@ class Engine:
         lib.taco_gru128_seq_bwd(dOUT, 256, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
                                 self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC,
                                 dXP, 768, HP, RH, N, T, 2, st)
+        self.flush_side()
         hw4 = b[sc + '/hw4']
         self.gemm_dw(hw4, dXP, self.G(sc + '/bigru/wx'), M, 128, 768)
         self.colsum(dXP, self.G(sc + '/bigru/bias'), M, 768)
@@ -393,6 +405,7 @@ class Engine:
             dXP = self.buf('dxp%d' % g, Ms, 768)
             lib.taco_gru256_seq_bwd(dD, self.P(sc + '/whg'), self.P(sc + '/whc'), R, U, C, Hh, dXP,
                                     self.xchg(N), self.err, N, S, st)
+            self.flush_side()
             self.gemm_dw(gin, dXP, self.G(sc + '/wx'), Ms, 256, 768)
             self.colsum(dXP, self.G(sc + '/bias'), Ms, 768)
             self.gemm_dw_shift(Hh, dXP, self.G(sc + '/whg'), Ms, S, 256, 512, 256, 768, 512)
@@ -405,6 +418,7 @@ class Engine:
         for k in ('dQ', 'dKEYS', 'dMEM', 'dVPART'):
             b[k].zero_()
         lib.taco_attn_rnn_bwd(self._attn_ptrs, self._attn_dims, st)
+        self.flush_side()
         HC, dXPa, dP2, dP1, dQ = b['HC'], b['dXPa'], b['dP2'], b['dP1'], b['dQ']
         self.gemm_dw(b['P2'], dXPa, self.G('attention_gru/wx'), Ms, 128, 768)
         self.colsum(dXPa, self.G('attention_gru/bias'), Ms, 768)
@@ -437,6 +451,7 @@ class Engine:
                                    self.gnorm2 if (self.tf_sparse_norm and self.world == 1) else None,
                                    N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
         if self._side_active:
+            self.flush_side()
             torch.cuda.current_stream().wait_stream(self.side_stream)      # join: all weight gradients are complete
             self._side_active = False
 
