@@ -279,43 +279,44 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 e = fmaf(vv.x, fast_tanh(kv.x + qv.x), e); e = fmaf(vv.y, fast_tanh(kv.y + qv.y), e);
                 e = fmaf(vv.z, fast_tanh(kv.z + qv.z), e); e = fmaf(vv.w, fast_tanh(kv.w + qv.w), e);
             }
-            e = dpp_add<0xB1>(e);
-            if (half == 0) { ep_l[i] = e; put_g(xE + (long)w * 2 * Ti + i, epoch, e); }
-        }
-        __syncthreads();
-        STAMP(10);
-        // gather + reduce the 8 partials of every (row,t) in workgroup order (bit-identical in all members)
-        for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
-            const int half = tid & 1;
+            e = dpp_add<0xB1>(e);                                  // both lanes of the pair now hold this workgroup's partial
+            if (half == 0) put_g(xE + (long)w * 2 * Ti + i, epoch, e);
+            // gather + reduce the 8 partials of (row,t) in workgroup order (bit-identical in all members); the own
+            // partial comes from the register, its slot is replaced by a dummy peer slot in the poll
             float val[4];
             const u64* ptr[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int pw = half * 4 + k;
-                ptr[k] = xE + (long)(pw == w ? ((w + 1) & 7) : pw) * 2 * Ti + i;       // own slot replaced by a dummy peer
+                ptr[k] = xE + (long)(pw == w ? ((w + 1) & 7) : pw) * 2 * Ti + i;
             }
             const u64* const cptr[4] = {ptr[0], ptr[1], ptr[2], ptr[3]};
             get_g<4>(cptr, epoch, val, p.err);
             float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? ep_l[i] : val[k];
+            for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? e : val[k];
             const float tot2 = dpp_add<0xB1>(sum);
             if (half == 0) a_l[i] = tot2;
         }
         __syncthreads();
+        STAMP(10);
         STAMP(11);
         // ================= G: softmax over all Ti (wave 0 -> row 0, wave 1 -> row 1) =================
         if (tid < 128) {
             const int row = tid >> 6, lane = tid & 63;
             float* ar = a_l + row * Ti;
+            float ev[8];                                   // Ti <= 512 values per row live in registers
             float mx = -INFINITY;
-            for (int t = lane; t < Ti; t += 64) mx = fmaxf(mx, ar[t]);
-            mx = wave_max(mx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int t = lane + 64 * i; ev[i] = t < Ti ? ar[t] : -INFINITY; mx = fmaxf(mx, ev[i]); }
+            mx = wave_max_fast(mx);
             float sm = 0.f;
-            for (int t = lane; t < Ti; t += 64) { const float x = __builtin_amdgcn_exp2f((ar[t] - mx) * 1.4426950408889634f); ar[t] = x; sm += x; }
-            sm = wave_sum(sm);
-            const float inv = 1.0f / sm;
-            for (int t = lane; t < Ti; t += 64) ar[t] *= inv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ev[i] = __builtin_amdgcn_exp2f((ev[i] - mx) * 1.4426950408889634f); sm += ev[i]; }
+            sm = wave_sum_fast(sm);
+            const float inv = __builtin_amdgcn_rcpf(sm);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int t = lane + 64 * i; if (t < Ti) ar[t] = ev[i] * inv; }
         }
         __syncthreads();
         STAMP(12);
@@ -329,9 +330,14 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             const int row = tid >> 8, tp = (tid >> 5) & 7, d = tid & 31;
             const float* ar = a_l + row * Ti;
             const float* mr = M_l + row * Ti * 32 + d;
-            float acc = 0.f;
-            for (int t = tp; t < Ti; t += 8) acc = fmaf(ar[t], mr[t * 32], acc);
-            cp_l[tp * 64 + row * 32 + d] = acc;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            int t = tp;
+            for (; t + 24 < Ti; t += 32) {                 // 4 independent LDS-load/FMA chains in flight
+                acc0 = fmaf(ar[t], mr[t * 32], acc0); acc1 = fmaf(ar[t + 8], mr[(t + 8) * 32], acc1);
+                acc2 = fmaf(ar[t + 16], mr[(t + 16) * 32], acc2); acc3 = fmaf(ar[t + 24], mr[(t + 24) * 32], acc3);
+            }
+            for (; t < Ti; t += 8) acc0 = fmaf(ar[t], mr[t * 32], acc0);
+            cp_l[tp * 64 + row * 32 + d] = (acc0 + acc1) + (acc2 + acc3);
         }
         __syncthreads();
         if (tid < 64) {
@@ -364,7 +370,7 @@ static size_t attn_cluster_smem(int Ti) {
 static size_t attn_cluster_bwd_smem(int Ti);
 extern "C" int taco_attn_cluster_supported(int N, int Ti) {
     return (CW * ((N + 1) / 2) <= 256 && attn_cluster_smem(Ti) <= 160 * 1024 && attn_cluster_bwd_smem(Ti) <= 160 * 1024 &&
-            Ti >= 1) ? 1 : 0;
+            Ti >= 1 && Ti <= 512) ? 1 : 0;
 }
 
 int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
@@ -541,11 +547,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 e = fmaf(mv.x, gv.x, e); e = fmaf(mv.y, gv.y, e); e = fmaf(mv.z, gv.z, e); e = fmaf(mv.w, gv.w, e);
             }
             e = dpp_add<0xB1>(e);
-            if (half == 0) { ep_l[i] = e; put_g(xDA + (long)w * 2 * Ti + i, epoch, e); }
-        }
-        __syncthreads();
-        for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
-            const int half = tid & 1;
+            if (half == 0) put_g(xDA + (long)w * 2 * Ti + i, epoch, e);
             float val[4];
             const u64* ptr[4];
 #pragma unroll
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             get_g<4>(cptr, epoch, val, p.err);
             float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? ep_l[i] : val[k];
+            for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? e : val[k];
             const float tot2 = dpp_add<0xB1>(sum);
             if (half == 0) de_l[i] = tot2;                        // da[row][t]
         }
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             const float* ar = a_l + row * Ti;
             float dot = 0.f;
             for (int t = lane; t < Ti; t += 64) dot = fmaf(ar[t], dr_[t], dot);
-            dot = wave_sum(dot);
+            dot = wave_sum_fast(dot);
             for (int t = lane; t < Ti; t += 64) dr_[t] = ar[t] * (dr_[t] - dot);
         }
         __syncthreads();
@@ -583,9 +585,14 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             const float* er = de_l + row * Ti;
             const float* kr = K_l + row * Ti * 32 + d;
             const float qd = q_l[row * 32 + d];
-            float acc = 0.f;
-            for (int t = tp; t < Ti; t += 8) { const float th = fast_tanh(kr[t * 32] + qd); acc = fmaf(er[t], 1.f - th * th, acc); }
-            cp_l[tp * 64 + row * 32 + d] = acc * vd;
+            float acc0 = 0.f, acc1 = 0.f;
+            int t = tp;
+            for (; t + 8 < Ti; t += 16) {
+                const float th0 = fast_tanh(kr[t * 32] + qd), th1 = fast_tanh(kr[(t + 8) * 32] + qd);
+                acc0 = fmaf(er[t], 1.f - th0 * th0, acc0); acc1 = fmaf(er[t + 8], 1.f - th1 * th1, acc1);
+            }
+            for (; t < Ti; t += 8) { const float th = fast_tanh(kr[t * 32] + qd); acc0 = fmaf(er[t], 1.f - th * th, acc0); }
+            cp_l[tp * 64 + row * 32 + d] = (acc0 + acc1) * vd;
         }
         __syncthreads();
         if (tid < 64) {

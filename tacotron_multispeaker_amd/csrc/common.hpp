@@ -60,6 +60,25 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// full-wave (64 lane) reductions without LDS round trips: DPP inside each 16-lane row, then the four row results are
+// combined through scalar registers (v_readlane)
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
+__device__ __forceinline__ float wave_max_fast(float v) {
+    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);
+    const int i = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+}
+
 // 64-lane wavefront reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
