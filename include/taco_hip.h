@@ -42,6 +42,13 @@ int taco_conv_gemm_bwd_weight(const float* X, const float* dY, float* dW, int M,
 int taco_gemm_tn_shift(const float* X, const float* dY, float* dW, int M, int T, int K, int N, int ldx, int lddy,
                        int ldw, int shift, hipStream_t stream);
 
+/* dense layer forward / input gradient over the step chunk [s0, s1) of [N,S,*] tensors (rows (n,s) live at n*S + s);
+ * lets the hoisted decoder projections be issued chunk by chunk between pipelined recurrence launches */
+int taco_dense_rows_fwd(const float* X, const float* W, const float* bias, float* Y, int N, int S, int s0, int s1, int Cin,
+                        int Cout, int ldx, int ldw, int ldy, int act, int accumulate, hipStream_t stream);
+int taco_dense_rows_bwd_data(const float* dY, const float* W, float* dX, int N, int S, int s0, int s1, int Cin, int Cout,
+                             int lddy, int ldw, int lddx, int accumulate, hipStream_t stream);
+
 /* ---- embeddings: tf.nn.embedding_lookup + speaker lookup/tile/concat (models/tacotron.py:42-55) -------------- */
 int taco_embed_gather_fwd(const int* ids, const int* identities, const float* table, const float* spk_table, float* out,
                           int N, int Ti, int Et, int Es, int vocab, int id_num, hipStream_t stream);
@@ -88,7 +95,9 @@ int taco_gru128_seq_bwd(const float* dout, int lddo, const float* wg_fw, const f
 
 /* ---- attention decoder (models/tacotron.py:66-97, rnn_wrappers.py, helpers.py:41-82) ---------------------------- */
 int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int num_mels, hipStream_t stream);
-/* attention recurrence; ptrs = device pointer table indexed by enum TacoAttnPtr, dims = {N, S, Ti} (host arrays) */
+/* attention recurrence; ptrs = device pointer table indexed by enum TacoAttnPtr, dims = {N, S, Ti, s0, s1} (host arrays);
+ * [s0, s1) = step range of this launch (cluster path only: chunks launched in order can be pipelined with the decoder GRUs;
+ * state passes through HC (forward) and the DHCARRY / DCTXCARRY slots (backward)); whole sequence: s0 = 0, s1 = S */
 int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 /* persistent-cluster path of the attention recurrence: shape support (1/0) and granule scratch size in 8-byte slots */
@@ -97,11 +106,15 @@ int taco_attn_cluster_xchg_slots(int N, int Ti);
 int taco_attn_cluster_bwd_xchg_slots(int N, int Ti);
 /* residual decoder GRU(256), whole recurrence in one persistent cluster launch (csrc/gru256.hip); hoisted input
  * projection xp [N,S,768]; d = res + h when d != NULL.  xchg: >= ceil(N/2)*6*256 8-byte granule slots of scratch,
- * err: device int set to 1 if a bounded spin ever times out (results are then invalid).  N <= 128. */
+ * err: device int set to 1 if a bounded spin ever times out (results are then invalid).  N <= 128.
+ * [s0, s1): step range of this launch -- the recurrence may be cut into chunks launched in order (forward: ascending,
+ * backward: descending) so that chunks of different recurrences can be pipelined on different streams; the state passes
+ * through h (forward) and carry [N,256] (backward). */
 int taco_gru256_seq_fwd(const float* xp, const float* whg, const float* whc, const float* res, float* r, float* u, float* c,
-                        float* rh, float* h, float* d, void* xchg, int* err, int N, int S, hipStream_t stream);
+                        float* rh, float* h, float* d, void* xchg, int* err, int N, int S, int s0, int s1, hipStream_t stream);
 int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, const float* r, const float* u, const float* c,
-                        const float* h, float* dxp, void* xchg, int* err, int N, int S, hipStream_t stream);
+                        const float* h, float* dxp, float* carry, void* xchg, int* err, int N, int S, int s0, int s1,
+                        hipStream_t stream);
 
 /* ---- optimizer: tf.clip_by_global_norm + tf.train.AdamOptimizer + Noam lr + BN UPDATE_OPS (tacotron.py:174-202) -- */
 int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream);

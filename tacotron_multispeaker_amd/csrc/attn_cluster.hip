@@ -154,12 +154,24 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     u64* X = p.xchg + (long)cl * per_clu;
     u64 *xCTX = X, *xP1 = X + 512, *xP2 = X + 1024, *xRH = X + 1280, *xH = X + 1792, *xE = X + 2304;
     float fnx0 = 0.f, fnx1 = 0.f;
-    if (pA == 0) { fnx0 = p.f1[(unsigned)(rw[0] * S) * 256u + 32 * w + cA]; fnx1 = p.f1[(unsigned)(rw[1] * S) * 256u + 32 * w + cA]; }
+    if (pA == 0) {
+        fnx0 = p.f1[(unsigned)(rw[0] * S + p.s0) * 256u + 32 * w + cA];
+        fnx1 = p.f1[(unsigned)(rw[1] * S + p.s0) * 256u + 32 * w + cA];
+    }
+    __syncthreads();
+    if (p.s0 > 0 && tid < 256) {                          // state of the previous chunk: h_{s0-1}, ctx_{s0-1}
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const unsigned o = (unsigned)(rw[b] * S + p.s0 - 1) * 512u;
+            h_l[b * PLEN(256) + PIDX(tid)] = p.hc[o + tid];
+            ctx_l[b * PLEN(256) + PIDX(tid)] = p.hc[o + 256u + tid];
+        }
+    }
     __syncthreads();
     STAMP_DECL
 
-    for (int s = 0; s < S; ++s) {
-        const unsigned epoch = (unsigned)s + 1;
+    for (int s = p.s0; s < p.s1; ++s) {
+        const unsigned epoch = (unsigned)(s - p.s0) + 1;
         STAMP(0);
         unsigned so0 = (unsigned)(rw[0] * S + s), so1 = (unsigned)(rw[1] * S + s);   // row offsets into [N,S,*] tensors
         asm volatile("" : "+v"(so0), "+v"(so1));      // opaque: addresses are formed at the point of use (see above)
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             const int j = 32 * w + cA;
             // frame part of dense_1 for this step was fetched one step ahead (HBM latency off the critical path)
             const float f0 = fnx0, f1v = fnx1;
-            if (pA == 0 && s + 1 < S) { fnx0 = p.f1[(so0 + 1u) * 256u + j]; fnx1 = p.f1[(so1 + 1u) * 256u + j]; }
+            if (pA == 0 && s + 1 < p.s1) { fnx0 = p.f1[(so0 + 1u) * 256u + j]; fnx1 = p.f1[(so1 + 1u) * 256u + j]; }
             float a0 = 0.f, a1 = 0.f;
             dot2<16>(ctx_l, ctx_l + PLEN(256), pA * 16, w1, a0, a1);
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
@@ -492,18 +504,22 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
 
     float dhc0 = 0.f, dhc1 = 0.f;      // dh carry   (owner lanes: pA == 0, index jA)
     float dcc0 = 0.f, dcc1 = 0.f;      // dctx carry (owner lanes: pA == 0, index jA)
+    if (p.s1 < S && pA == 0) {         // chunked launch: state of the later chunk
+        dhc0 = p.dhcarry[(unsigned)rw[0] * 256u + jA]; dhc1 = p.dhcarry[(unsigned)rw[1] * 256u + jA];
+        dcc0 = p.dctxcarry[(unsigned)rw[0] * 256u + jA]; dcc1 = p.dctxcarry[(unsigned)rw[1] * 256u + jA];
+    }
     // one-step-ahead prefetch registers, primed for s = S-1
     float pf_a = 0.f, pf_q = 0.f, pf_r[2] = {0, 0}, pf_u[2] = {0, 0}, pf_c[2] = {0, 0}, pf_hp[2] = {0, 0}, pf_dhe[2] = {0, 0},
           pf_dce[2] = {0, 0}, pf_p1[2] = {0, 0}, pf_p2[2] = {0, 0};
     {
-        const unsigned sl[2] = {(unsigned)(rw[0] * S + S - 1), (unsigned)(rw[1] * S + S - 1)};
+        const unsigned sl[2] = {(unsigned)(rw[0] * S + p.s1 - 1), (unsigned)(rw[1] * S + p.s1 - 1)};
         if (2 * Ti <= AT && tid < 2 * Ti) { const int row = tid >= Ti; pf_a = p.align[sl[row] * (unsigned)Ti + (tid - row * Ti)]; }
         if (tid < 64) pf_q = p.q[sl[tid >> 5] * 256u + 32 * w + (tid & 31)];
         if (pA == 0) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 pf_r[b] = p.r[sl[b] * 256u + jA]; pf_u[b] = p.u[sl[b] * 256u + jA]; pf_c[b] = p.c[sl[b] * 256u + jA];
-                pf_hp[b] = S > 1 ? p.hc[(sl[b] - 1u) * 512u + jA] : 0.f;
+                pf_hp[b] = p.s1 > 1 ? p.hc[(sl[b] - 1u) * 512u + jA] : 0.f;
                 pf_dhe[b] = p.dhc[sl[b] * 512u + jA]; pf_dce[b] = p.dhc[sl[b] * 512u + 256u + jA];
                 pf_p1[b] = p.p1[sl[b] * 256u + jA];
             }
@@ -512,8 +528,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     }
     __syncthreads();
 
-    for (int s = S - 1; s >= 0; --s) {
-        const unsigned epoch = (unsigned)(S - s);
+    for (int s = p.s1 - 1; s >= p.s0; --s) {
+        const unsigned epoch = (unsigned)(p.s1 - s);
         unsigned so[2] = {(unsigned)(rw[0] * S + s), (unsigned)(rw[1] * S + s)};
         asm volatile("" : "+v"(so[0]), "+v"(so[1]));   // opaque per-step offsets: no precomputed 64-bit addresses kept live
         // ---- this step's saved activations / external gradients were fetched ONE STEP AHEAD (registers), so their HBM
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         }
         __syncthreads();
         // ---- issue the loads for step s-1 (consumed at the top of the next iteration)
-        if (s > 0) {
+        if (s > p.s0) {
             const unsigned sn[2] = {so[0] - 1u, so[1] - 1u};
             if (2 * Ti <= AT && tid < 2 * Ti) { const int row = tid >= Ti; pf_a = p.align[sn[row] * (unsigned)Ti + (tid - row * Ti)]; }
             if (tid < 64) pf_q = p.q[sn[tid >> 5] * 256u + 32 * w + (tid & 31)];
@@ -698,7 +714,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             gather_vec<32>(xDP1, dp1_l, dp1_l + PLEN(256), w, epoch, tid, p.err);
         }
         __syncthreads();
-        if (s > 0) {
+        if (s > p.s0) {
             if (pA == 0) { pf_p1[0] = p.p1[(so[0] - 1u) * 256u + jA]; pf_p1[1] = p.p1[(so[1] - 1u) * 256u + jA]; }
             if (pB == 0) { pf_p2[0] = p.p2[(so[0] - 1u) * 128u + jB]; pf_p2[1] = p.p2[(so[1] - 1u) * 128u + jB]; }
         }
@@ -710,6 +726,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             if (pA == 0) { dcc0 = a0; dcc1 = a1; }
         }
         // (the next iteration's first LDS writes -- a_l, q_l, dctx_l -- are not read by X8: no barrier needed here)
+    }
+    if (p.s0 > 0 && pA == 0) {         // hand the carries to the launch of the previous chunk
+        if (ok[0]) { p.dhcarry[(unsigned)rw[0] * 256u + jA] = dhc0; p.dctxcarry[(unsigned)rw[0] * 256u + jA] = dcc0; }
+        if (ok[1]) { p.dhcarry[(unsigned)rw[1] * 256u + jA] = dhc1; p.dctxcarry[(unsigned)rw[1] * 256u + jA] = dcc1; }
     }
 }
 
@@ -763,7 +783,8 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
     if (attn_cluster_bwd_smem(p.Ti) > 160 * 1024) return TACO_EINVAL;
     if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
     hipLaunchKernelGGL(attn_cluster_bwd_k, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti), st, p);
-    hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3(p.Ti, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v, dkeys,
-                       dmem, dvpart, p.S, p.Ti);
+    if (p.s0 == 0)       // all chunks done: reduce over the S steps
+        hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3(p.Ti, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
+                           dkeys, dmem, dvpart, p.S, p.Ti);
     TACO_RETURN_LAST();
 }

@@ -6,14 +6,15 @@ struct AttnClu {
     const float *w1c, *f1, *w2, *b2, *wx, *whg, *whc, *bg, *wq, *v, *keys, *mem;
     float *p1, *p2, *r, *u, *c, *rh, *hc, *q, *align;
     u64* xchg; int* err;
-    int N, S, Ti;
+    int N, S, Ti, s0, s1;
 };
 int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st);
 struct AttnCluB {
     const float *w1c, *w2, *wx, *whg, *whc, *wq, *v, *keys, *mem;
     const float *p1, *p2, *r, *u, *c, *hc, *q, *align, *dhc;
     float *dxp, *dp2, *dp1, *dq, *de, *dctx;
+    float *dhcarry, *dctxcarry;      // [N,256] each: state handed between chunk launches
     u64* xchg; int* err;
-    int N, S, Ti;
+    int N, S, Ti, s0, s1;
 };
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st);

@@ -489,9 +489,11 @@ extern "C" int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipSt
         p.p1 = G(TACO_AP_P1); p.p2 = G(TACO_AP_P2); p.r = G(TACO_AP_R); p.u = G(TACO_AP_U); p.c = G(TACO_AP_C);
         p.rh = G(TACO_AP_RH); p.hc = G(TACO_AP_HC); p.q = G(TACO_AP_Q); p.align = G(TACO_AP_ALIGN);
         p.xchg = (u64*)const_cast<void*>(ptrs[TACO_AP_XCHG]); p.err = (int*)const_cast<void*>(ptrs[TACO_AP_ERR]);
-        p.N = N; p.S = S; p.Ti = Ti;
+        p.N = N; p.S = S; p.Ti = Ti; p.s0 = dims[3]; p.s1 = dims[4];
+        if (p.s0 < 0 || p.s1 > S || p.s0 >= p.s1) return TACO_EINVAL;
         return attn_cluster_fwd_launch(p, st);
     }
+    if (dims[3] != 0 || dims[4] != S) return TACO_EINVAL;      // the per-stage fallback runs whole sequences only
     return attn_rnn_fwd_steps(ptrs, dims, st);
 }
 
@@ -512,8 +514,11 @@ extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipSt
         p.dxp = G(TACO_AP_DXP); p.dp2 = G(TACO_AP_DP2); p.dp1 = G(TACO_AP_DP1); p.dq = G(TACO_AP_DQ);
         p.de = G(TACO_AP_DE); p.dctx = G(TACO_AP_DCTXS);
         p.xchg = (u64*)const_cast<void*>(ptrs[TACO_AP_XCHG]); p.err = (int*)const_cast<void*>(ptrs[TACO_AP_ERR]);
-        p.N = N; p.S = S; p.Ti = Ti;
+        p.dhcarry = G(TACO_AP_DHCARRY); p.dctxcarry = G(TACO_AP_DCTXCARRY);
+        p.N = N; p.S = S; p.Ti = Ti; p.s0 = dims[3]; p.s1 = dims[4];
+        if (p.s0 < 0 || p.s1 > S || p.s0 >= p.s1) return TACO_EINVAL;
         return attn_cluster_bwd_launch(p, G(TACO_AP_DKEYS), G(TACO_AP_DMEM), G(TACO_AP_DVPART), st);
     }
+    if (dims[3] != 0 || dims[4] != S) return TACO_EINVAL;
     return attn_rnn_bwd_steps(ptrs, dims, st);
 }

@@ -26,7 +26,13 @@ struct ConvGemm {
     int accumulate;     // NN/NT: C += result
     int splitk;         // TN: reduction split
     int shift0;         // TN: extra row shift of X (dW of recurrent weights: X = H shifted by one step)
+    int rb_len, rb_stride, rb_off;   // NN/NT row blocking: logical row m -> physical row (m / rb_len) * rb_stride + rb_off + m % rb_len
+                                     // (a chunk of steps [s0, s0+rb_len) of [N,S,*] tensors seen as one [N*rb_len, *] matrix); 0 = identity
 };
+
+__device__ __forceinline__ long rowmap(const ConvGemm& p, int m) {
+    return p.rb_len ? (long)(m / p.rb_len) * p.rb_stride + p.rb_off + (m % p.rb_len) : (long)m;
+}
 
 // ---- MFMA inner product on one staged K-tile -------------------------------------------------------
 // A tile: k-contiguous [BM][BK+4] (AKC) or k-strided [BK][BM];  B tile likewise with BN.
@@ -134,7 +140,7 @@ __device__ __forceinline__ void epilogue_store(const ConvGemm& p, f32x16 (&acc)[
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < p.M) {
-                    float* c = p.C + (long)row * p.ldc + col;
+                    float* c = p.C + rowmap(p, row) * p.ldc + col;
                     float v = apply_act(acc[mi][ni][r] + bv, p.act);
                     if (p.accumulate) v += *c;
                     *c = v;
@@ -173,8 +179,9 @@ __global__ __launch_bounds__(256) void conv_gemm_nn(ConvGemm p) {
     const int nsteps = kw * ksteps;
 
     int tpos[TA::NV];
+    long arow[TA::NV];
 #pragma unroll
-    for (int v = 0; v < TA::NV; ++v) tpos[v] = (m0 + TA::row(tid, v)) % p.T;
+    for (int v = 0; v < TA::NV; ++v) { tpos[v] = (m0 + TA::row(tid, v)) % p.T; arow[v] = rowmap(p, m0 + TA::row(tid, v)); }
 
     f32x16 acc[BM / 64][BN / 64];
 #pragma unroll
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nn(ConvGemm p) {
             const int grow = m0 + TA::row(tid, v);
             const int k = kc * BK + TA::c4(tid, v) * 4;
             const bool ok = grow < p.M && k < p.K && (unsigned)(tpos[v] + shift) < (unsigned)p.T;
-            ra[v] = ld4(p.A + (long)(grow + shift) * p.lda + k, ok);
+            ra[v] = ld4(p.A + (arow[v] + shift) * p.lda + k, ok);
         }
         const float* Wj = Bb + (long)j * p.K * ldb;
 #pragma unroll
@@ -237,8 +244,9 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
     const int ksteps = (p.K + BK - 1) / BK;
 
     int tpos[TA::NV];
+    long arow[TA::NV];
 #pragma unroll
-    for (int v = 0; v < TA::NV; ++v) tpos[v] = (m0 + TA::row(tid, v)) % p.T;
+    for (int v = 0; v < TA::NV; ++v) { tpos[v] = (m0 + TA::row(tid, v)) % p.T; arow[v] = rowmap(p, m0 + TA::row(tid, v)); }
 
     f32x16 acc[BM / 64][BN / 64];
 #pragma unroll
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
             const int grow = m0 + TA::row(tid, v);
             const int k = kc * BK + TA::c4(tid, v) * 4;
             const bool ok = grow < p.M && k < p.K && (unsigned)(tpos[v] + shift) < (unsigned)p.T;
-            ra[v] = ld4(p.A + (long)(grow + shift) * p.lda + aoff + k, ok);
+            ra[v] = ld4(p.A + (arow[v] + shift) * p.lda + aoff + k, ok);
         }
 #pragma unroll
         for (int v = 0; v < TB::NV; ++v) {
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < p.M) atomicAdd(p.C + (long)row * p.ldc + col, acc[mi][ni][r]);
+                if (row < p.M) atomicAdd(p.C + rowmap(p, row) * p.ldc + col, acc[mi][ni][r]);
             }
     }
 }
@@ -513,4 +521,35 @@ extern "C" int taco_conv_gemm_bwd_weight(const float* X, const float* dY, float*
 extern "C" int taco_gemm_tn_shift(const float* X, const float* dY, float* dW, int M, int T, int K, int N, int ldx, int lddy,
                                   int ldw, int shift, hipStream_t stream) {
     return conv_gemm_bwd_weight_impl(X, dY, dW, M, T, K, N, 1, 0, ldx, lddy, ldw, shift, stream);
+}
+
+// Dense layers over a CHUNK of steps of [N,S,*] tensors: logical rows (n, s) with s in [s0, s1), physical row n*S + s.
+// Used to pipeline the decoder recurrences chunk by chunk (engine.py); both X and Y / dY and dX use the [N,S,*] layout.
+extern "C" int taco_dense_rows_fwd(const float* X, const float* W, const float* bias, float* Y, int N, int S, int s0, int s1,
+                                   int Cin, int Cout, int ldx, int ldw, int ldy, int act, int accumulate, hipStream_t stream) {
+    ConvGemm p{};
+    const int ch = s1 - s0, M = N * ch;
+    p.A = X; p.B = W; p.C = Y; p.bias = bias;
+    p.M = M; p.N = Cout; p.K = Cin; p.T = M > 0 ? M : 1; p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.act = act; p.accumulate = accumulate;
+    p.splitk = 1; p.kw_lo = p.kw_hi = 1; p.rb_len = ch; p.rb_stride = S; p.rb_off = s0;
+    if (ch <= 0 || s0 < 0 || s1 > S) return TACO_EINVAL;
+    if (int e = check_common(p)) return e;
+    if (p.K & 3) return TACO_EINVAL;
+    dim3 g(cdiv(M, 64), cdiv(p.N, 64));
+    hipLaunchKernelGGL((conv_gemm_nn<64, 64, 32>), g, dim3(256), 0, stream, p);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_dense_rows_bwd_data(const float* dY, const float* W, float* dX, int N, int S, int s0, int s1, int Cin,
+                                        int Cout, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream) {
+    ConvGemm p{};
+    const int ch = s1 - s0, M = N * ch;
+    p.A = dY; p.B = W; p.C = dX; p.bias = nullptr;
+    p.M = M; p.N = Cin; p.K = Cout; p.T = M > 0 ? M : 1; p.lda = lddy; p.ldb = ldw; p.ldc = lddx; p.act = ACT_NONE;
+    p.accumulate = accumulate; p.splitk = 1; p.kw_lo = p.kw_hi = 1; p.rb_len = ch; p.rb_stride = S; p.rb_off = s0;
+    if (ch <= 0 || s0 < 0 || s1 > S) return TACO_EINVAL;
+    if (int e = check_common(p)) return e;
+    dim3 g(cdiv(M, 64), cdiv(p.N, 64), 1);
+    hipLaunchKernelGGL((conv_gemm_nt<64, 64, 32>), g, dim3(256), 0, stream, p);
+    TACO_RETURN_LAST();
 }

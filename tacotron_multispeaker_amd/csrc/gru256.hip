@@ -53,9 +53,11 @@ struct Gru256 {
     u64* xchg;            // granule regions (zeroed before launch)
     int* err;
     int N, S;
+    int s0, s1;           // step range [s0, s1) of this launch (chunked pipelining); state enters / leaves through h / carry
     // backward
     const float* dout;    // [N,S,256]
     float* dxp;           // [N,S,768]
+    float* carry;         // [N,256] recurrent part of dh carried between chunk launches (dout is added by the consumer)
 };
 
 // gather one value per row from each of the 3 peers' 64-slices of a [2][256] granule region into QIDX LDS vectors
@@ -97,11 +99,15 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
 #pragma unroll
     for (int k = 0; k < 32; ++k) wc[k] = p.whc[(long)(k8 * 32 + k) * 256 + 64 * w + ccol];
 
-    for (int i = tid; i < 2 * QLEN(HD); i += GT2) { (&h_l[0][0])[i] = 0.0f; (&rh_l[0][0])[i] = 0.0f; }
-    __syncthreads();
-
     const bool ok0 = row0 < p.N, ok1 = row0 + 1 < p.N;
     const unsigned rb0 = (unsigned)(min(row0, p.N - 1) * p.S), rb1 = (unsigned)(min(row0 + 1, p.N - 1) * p.S);
+    for (int i = tid; i < 2 * QLEN(HD); i += GT2) { (&h_l[0][0])[i] = 0.0f; (&rh_l[0][0])[i] = 0.0f; }
+    __syncthreads();
+    if (p.s0 > 0 && tid < HD) {                           // state of the previous chunk
+        h_l[0][QIDX(tid)] = p.h[(rb0 + p.s0 - 1) * 256u + tid];
+        h_l[1][QIDX(tid)] = p.h[(rb1 + p.s0 - 1) * 256u + tid];
+    }
+    __syncthreads();
     u64* xr = p.xchg + ((long)cl * 2) * HD;                               // rh granules  [2][256]
     u64* xh = p.xchg + ((long)nclus * 2 + (long)cl * 2) * HD;             // h' granules
     const int j_own = 64 * w + (gcol & 63);                               // hidden index of this thread's gate column
@@ -109,15 +115,15 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
 
     // input projections are fetched one step ahead
     float nxg0 = 0.f, nxg1 = 0.f, nxc0 = 0.f, nxc1 = 0.f;
-    if (kq == 0) { nxg0 = p.xp[rb0 * 768u + gc]; nxg1 = p.xp[rb1 * 768u + gc]; }
-    if (k8 == 0) { nxc0 = p.xp[rb0 * 768u + 512u + jc]; nxc1 = p.xp[rb1 * 768u + 512u + jc]; }
+    if (kq == 0) { nxg0 = p.xp[(rb0 + p.s0) * 768u + gc]; nxg1 = p.xp[(rb1 + p.s0) * 768u + gc]; }
+    if (k8 == 0) { nxc0 = p.xp[(rb0 + p.s0) * 768u + 512u + jc]; nxc1 = p.xp[(rb1 + p.s0) * 768u + 512u + jc]; }
 
-    for (int s = 0; s < p.S; ++s) {
-        const unsigned epoch = (unsigned)s + 1;
+    for (int s = p.s0; s < p.s1; ++s) {
+        const unsigned epoch = (unsigned)(s - p.s0) + 1;
         unsigned o0 = rb0 + s, o1 = rb1 + s;
         asm volatile("" : "+v"(o0), "+v"(o1));           // opaque: store addresses are formed at the point of use
         const float xg0 = nxg0, xg1 = nxg1, xc0 = nxc0, xc1 = nxc1;
-        if (s + 1 < p.S) {
+        if (s + 1 < p.s1) {
             if (kq == 0) { nxg0 = p.xp[(o0 + 1u) * 768u + gc]; nxg1 = p.xp[(o1 + 1u) * 768u + gc]; }
             if (k8 == 0) { nxc0 = p.xp[(o0 + 1u) * 768u + 512u + jc]; nxc1 = p.xp[(o1 + 1u) * 768u + 512u + jc]; }
         }
@@ -229,22 +235,24 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
     u64* xgu = p.xchg + ((long)nclus * 4) * HD + ((long)cl * 2) * HD;        // dg_u granules [2][256]
     const bool owner = j8 == 0;
 
-    float dhT[2] = {0.f, 0.f};
+    float dhT[2] = {0.f, 0.f}, dhn[2] = {0.f, 0.f};
     // saved activations of the step are fetched one step ahead
     float pr[2] = {0, 0}, pu[2] = {0, 0}, pc[2] = {0, 0}, ph[2] = {0, 0}, pdo[2] = {0, 0};
     if (owner) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const unsigned o = rb[b] + p.S - 1;
-            dhT[b] = p.dout[o * 256u + k_own];
+            const unsigned o = rb[b] + p.s1 - 1;
+            // gradient wrt h_{s1-1}: external part (read now: a pipelined producer finishes it just before this launch)
+            // plus the recurrent part handed over by the launch of the later chunk
+            dhT[b] = p.dout[o * 256u + k_own] + (p.s1 == p.S ? 0.f : p.carry[(unsigned)min(row0 + b, p.N - 1) * 256u + k_own]);
             pr[b] = p.r[o * 256u + k_own]; pu[b] = p.u[o * 256u + k_own]; pc[b] = p.c[o * 256u + k_own];
-            ph[b] = p.S > 1 ? p.h[(o - 1u) * 256u + k_own] : 0.f;
-            pdo[b] = p.S > 1 ? p.dout[(o - 1u) * 256u + k_own] : 0.f;
+            ph[b] = p.s1 > 1 ? p.h[(o - 1u) * 256u + k_own] : 0.f;
+            pdo[b] = p.s1 > 1 ? p.dout[(o - 1u) * 256u + k_own] : 0.f;
         }
     }
 
-    for (int s = p.S - 1; s >= 0; --s) {
-        const unsigned epoch = (unsigned)(p.S - s);
+    for (int s = p.s1 - 1; s >= p.s0; --s) {
+        const unsigned epoch = (unsigned)(p.s1 - s);
         unsigned o[2] = {rb[0] + s, rb[1] + s};
         asm volatile("" : "+v"(o[0]), "+v"(o[1]));
         float r_[2], u_[2], c_[2], hp_[2], don[2], du[2] = {0.f, 0.f}, dhd[2] = {0.f, 0.f};
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
                 put_granule(xc + b * HD + k_own, epoch, dcp);
                 if (ok[b]) p.dxp[o[b] * 768u + 512u + k_own] = dcp;
             }
-            if (s > 0) {                                   // prefetch step s-1
+            if (s > p.s0) {                                // prefetch step s-1
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const unsigned on = o[b] - 1u;
@@ -337,9 +345,13 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
             }
         }
         e0 = group_sum<8>(e0); e1 = group_sum<8>(e1);
-        if (owner) { dhT[0] = dhp[0] + e0 + don[0]; dhT[1] = dhp[1] + e1 + don[1]; }
+        if (owner) { dhn[0] = dhp[0] + e0; dhn[1] = dhp[1] + e1; dhT[0] = dhn[0] + don[0]; dhT[1] = dhn[1] + don[1]; }
         // no trailing barrier: the dcp slots rewritten at the top of the next iteration were last read before this
         // iteration's second barrier, and the gate-gradient slots are rewritten only after the next barrier
+    }
+    if (p.s0 > 0 && owner) {                               // recurrent part of the gradient wrt h_{s0-1} for the next launch
+        if (ok[0]) p.carry[(unsigned)row0 * 256u + k_own] = dhn[0];
+        if (ok[1]) p.carry[(unsigned)(row0 + 1) * 256u + k_own] = dhn[1];
     }
 }
 
@@ -347,30 +359,32 @@ static int gru256_grid(int N) { return 4 * ((N + 1) / 2); }
 
 extern "C" int taco_gru256_seq_fwd(const float* xp, const float* whg, const float* whc, const float* res, float* r, float* u,
                                    float* c, float* rh, float* h, float* d, void* xchg, int* err, int N, int S,
-                                   hipStream_t st) {
+                                   int s0, int s1, hipStream_t st) {
     if (!xp || !whg || !whc || !r || !u || !c || !rh || !h || !xchg || !err || N <= 0 || S <= 0) return TACO_EINVAL;
+    if (s0 < 0 || s1 > S || s0 >= s1) return TACO_EINVAL;
     if (d && !res) return TACO_EINVAL;
     if (gru256_grid(N) > 256) return TACO_EINVAL;           // all workgroups must be co-resident
     const int nclus = (N + 1) / 2;
     if (hipMemsetAsync(xchg, 0, (size_t)nclus * 2 * 2 * HD * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
     Gru256 p{};
     p.xp = xp; p.whg = whg; p.whc = whc; p.res = res; p.r = r; p.u = u; p.c = c; p.rh = rh; p.h = h; p.d = d;
-    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S;
+    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1;
     hipLaunchKernelGGL(gru256_cluster_fwd_k, dim3(gru256_grid(N)), dim3(GT2), 0, st, p);
     TACO_RETURN_LAST();
 }
 
 extern "C" int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, const float* r, const float* u,
-                                   const float* c, const float* h, float* dxp, void* xchg, int* err, int N, int S,
-                                   hipStream_t st) {
-    if (!dout || !whg || !whc || !r || !u || !c || !h || !dxp || !xchg || !err || N <= 0 || S <= 0) return TACO_EINVAL;
+                                   const float* c, const float* h, float* dxp, float* carry, void* xchg, int* err, int N,
+                                   int S, int s0, int s1, hipStream_t st) {
+    if (!dout || !whg || !whc || !r || !u || !c || !h || !dxp || !carry || !xchg || !err || N <= 0 || S <= 0) return TACO_EINVAL;
+    if (s0 < 0 || s1 > S || s0 >= s1) return TACO_EINVAL;
     if (gru256_grid(N) > 256) return TACO_EINVAL;
     const int nclus = (N + 1) / 2;
     if (hipMemsetAsync(xchg, 0, (size_t)nclus * 2 * 3 * HD * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
     Gru256 p{};
     p.dout = dout; p.whg = whg; p.whc = whc; p.r = const_cast<float*>(r); p.u = const_cast<float*>(u);
     p.c = const_cast<float*>(c); p.h = const_cast<float*>(h); p.dxp = dxp;
-    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S;
+    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1; p.carry = carry;
     hipLaunchKernelGGL(gru256_cluster_bwd_k, dim3(gru256_grid(N)), dim3(GT2), 0, st, p);
     TACO_RETURN_LAST();
 }

@@ -7,6 +7,7 @@ host<->device synchronisation, so a full step can be captured into a HIP graph (
 Reference being replaced: the TF-1 graph built by models/tacotron.py:35-195 and run at train.py:142-146.
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -57,6 +58,9 @@ class Engine:
         self.side_stream = torch.cuda.Stream(device=self.dev)
         self._side_active = False
         self._deferred = []
+        self.stream_b = torch.cuda.Stream(device=self.dev)      # decoder pipeline stages (GRU1 / GRU2 or attention)
+        self.stream_c = torch.cuda.Stream(device=self.dev)
+        self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.overlap_wgrad = True
         self.world = 1
         self.load_named(named_params if named_params is not None else init_named(L, seed))
@@ -299,20 +303,39 @@ class Engine:
         self.gemm(FR, W1, self.P('decoder_prenet/dense_1/bias'), F1, Ms, nm, 256)
         z = self.buf('zeros', max(N, 32) * 256)
         self._attn_ptrs = self._make_attn_ptrs(N, S, Ti)
-        lib.taco_attn_rnn_fwd(self._attn_ptrs, self._attn_dims, st)
         HC = self._bufs['HC']
         Y = self.buf('Y', Ms, 256)
-        self.dense_fwd(HC, 'concat_projection', Y, Ms, 512, 256)
-        prev = Y
+        gb = {}
         for g in (1, 2):
-            sc = 'decoder_gru_%d' % g
-            XP = self.buf('xp%d' % g, Ms, 768)
-            self.gemm(prev, self.P(sc + '/wx'), self.P(sc + '/bias'), XP, Ms, 256, 768)
-            t = [self.buf('g%d_%s' % (g, k), Ms, 256) for k in ('r', 'u', 'c', 'rh', 'h')]
-            D = self.buf('D%d' % g, Ms, 256)
-            lib.taco_gru256_seq_fwd(XP, self.P(sc + '/whg'), self.P(sc + '/whc'), prev, t[0], t[1], t[2], t[3], t[4], D,
-                                    self.xchg(N), self.err, N, S, st)
-            prev = D
+            gb[g] = dict(XP=self.buf('xp%d' % g, Ms, 768), D=self.buf('D%d' % g, Ms, 256),
+                         t=[self.buf('g%d_%s' % (g, k), Ms, 256) for k in ('r', 'u', 'c', 'rh', 'h')],
+                         x=self.buf('xchg_g%d' % g, ((N + 1) // 2) * 16 * 256, dtype=torch.int64))
+        # Chunk-pipelined decoder: attention recurrence on the current stream, GRU1 / GRU2 on two more streams; chunk c
+        # of GRU1 (its hoisted projections first) starts as soon as the attention kernel has finished chunk c.
+        chunks = self._chunks(N, S, Ti)
+        cur = torch.cuda.current_stream()
+        sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
+        Wp, bp = self.P('concat_projection/kernel'), self.P('concat_projection/bias')
+        for (s0, s1) in chunks:
+            lib.taco_attn_rnn_fwd(self._attn_ptrs, self._dims(N, S, Ti, s0, s1), self.st)
+            ev = torch.cuda.Event(); ev.record(cur)
+            sb.wait_event(ev)
+            with torch.cuda.stream(sb):
+                self.dense_rows(HC, Wp, bp, Y, N, S, s0, s1, 512, 256, 512, 256)
+                self.dense_rows(Y, self.P('decoder_gru_1/wx'), self.P('decoder_gru_1/bias'), gb[1]['XP'], N, S, s0, s1, 256, 768, 256, 768)
+                t = gb[1]['t']
+                lib.taco_gru256_seq_fwd(gb[1]['XP'], self.P('decoder_gru_1/whg'), self.P('decoder_gru_1/whc'), Y, t[0], t[1], t[2],
+                                        t[3], t[4], gb[1]['D'], gb[1]['x'], self.err, N, S, s0, s1, self.st)
+                ev2 = torch.cuda.Event(); ev2.record(sb)
+            sc_.wait_event(ev2)
+            with torch.cuda.stream(sc_):
+                self.dense_rows(gb[1]['D'], self.P('decoder_gru_2/wx'), self.P('decoder_gru_2/bias'), gb[2]['XP'], N, S, s0, s1, 256, 768, 256, 768)
+                t = gb[2]['t']
+                lib.taco_gru256_seq_fwd(gb[2]['XP'], self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), gb[1]['D'], t[0], t[1],
+                                        t[2], t[3], t[4], gb[2]['D'], gb[2]['x'], self.err, N, S, s0, s1, self.st)
+        if len(chunks) > 1:
+            cur.wait_stream(sb); cur.wait_stream(sc_)
+        prev = gb[2]['D']
         MEL = self.buf('mel_out', N, To, nm)             # == decoder outputs [N,S,nm*r] (tacotron.py:97)
         self.dense_fwd(prev, 'output_projection', MEL.view(Ms, nm * r), Ms, 256, nm * r)
         POST = self.cbhg_fwd('post_cbhg', MEL.view(Mp, nm), N, To, nm, 8, (256, nm), None, training)
@@ -322,6 +345,23 @@ class Engine:
         self.alignments = self._bufs['ALIGN'].view(N, S, Ti).transpose(1, 2)      # [N, Ti, S] (tacotron.py:104)
         self.encoder_outputs = ENC.view(N, Ti, 256)
         return MEL, LIN, self.alignments
+
+    def _chunks(self, N, S, Ti):
+        """Step ranges for the chunk-pipelined decoder (needs the cluster path); [(0, S)] = no pipelining."""
+        k = self.pipe_chunks
+        if k <= 1 or S < 2 * k or not lib.load().taco_attn_cluster_supported(N, Ti):
+            return [(0, S)]
+        step = (S + k - 1) // k
+        return [(s, min(S, s + step)) for s in range(0, S, step)]
+
+    def _dims(self, N, S, Ti, s0, s1):
+        return (ctypes.c_int * 5)(N, S, Ti, s0, s1)
+
+    def dense_rows(self, x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, ldy):
+        lib.taco_dense_rows_fwd(x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, cout, ldy, 0, 0, self.st)
+
+    def dense_rows_dx(self, dy, w, dx, N, S, s0, s1, cin, cout, lddy, lddx, acc):
+        lib.taco_dense_rows_bwd_data(dy, w, dx, N, S, s0, s1, cin, cout, lddy, cout, lddx, acc, self.st)
 
     def _attn_slots(self, N, Ti):
         dll = lib.load()
@@ -396,29 +436,52 @@ class Engine:
         D2 = b['D2']
         dD = self.buf('dD2', Ms, 256)
         self.dense_bwd(D2, dOUT, 'output_projection', Ms, 256, nm * r, dx=dD)
-        z = b['zeros']
-        # residual GRUs, top to bottom
+        # Chunk-pipelined decoder backward (descending chunks): GRU2 BPTT on the current stream, GRU1 BPTT and the attention
+        # BPTT on two more streams; the hoisted input-gradient projections of a chunk run between the stages.
+        chunks = self._chunks(N, S, Ti)[::-1]
+        cur = torch.cuda.current_stream()
+        sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
+        dHC = b['dHC']
+        for k in ('dQ', 'dKEYS', 'dMEM', 'dVPART'):
+            b[k].zero_()
+        dxp = {g: self.buf('dxp%d' % g, Ms, 768) for g in (1, 2)}
+        car = {g: self.buf('gcarry%d' % g, N, 256) for g in (1, 2)}
+        xg = {g: b['xchg_g%d' % g] for g in (1, 2)}
+        Wp = self.P('concat_projection/kernel')
+        first = True
+        for (s0, s1) in chunks:
+            R, U, C, RH, Hh = (b['g2_%s' % k] for k in ('r', 'u', 'c', 'rh', 'h'))
+            lib.taco_gru256_seq_bwd(dD, self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), R, U, C, Hh, dxp[2], car[2],
+                                    xg[2], self.err, N, S, s0, s1, self.st)
+            if first:
+                self.flush_side()          # post-net weight gradients fill the CUs the recurrences leave idle
+                first = False
+            ev = torch.cuda.Event(); ev.record(cur)
+            sb.wait_event(ev)
+            with torch.cuda.stream(sb):
+                self.dense_rows_dx(dxp[2], self.P('decoder_gru_2/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dD1 = dD2 + dxp2.Wx2^T
+                R, U, C, RH, Hh = (b['g1_%s' % k] for k in ('r', 'u', 'c', 'rh', 'h'))
+                lib.taco_gru256_seq_bwd(dD, self.P('decoder_gru_1/whg'), self.P('decoder_gru_1/whc'), R, U, C, Hh, dxp[1], car[1],
+                                        xg[1], self.err, N, S, s0, s1, self.st)
+                ev2 = torch.cuda.Event(); ev2.record(sb)
+            sc_.wait_event(ev2)
+            with torch.cuda.stream(sc_):
+                self.dense_rows_dx(dxp[1], self.P('decoder_gru_1/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dY = dD1 + dxp1.Wx1^T
+                self.dense_rows_dx(dD, Wp, dHC, N, S, s0, s1, 512, 256, 256, 512, 0)                               # d[h|ctx] = dY.Wp^T
+                lib.taco_attn_rnn_bwd(self._attn_ptrs, self._dims(N, S, Ti, s0, s1), self.st)
+        if len(chunks) > 1:
+            cur.wait_stream(sb); cur.wait_stream(sc_)
+        dY = dD
+        # weight gradients of the decoder (deferred to the side stream)
         for g in (2, 1):
             sc = 'decoder_gru_%d' % g
             gin = b['D1'] if g == 2 else b['Y']
-            R, U, C, RH, Hh = (b['g%d_%s' % (g, k)] for k in ('r', 'u', 'c', 'rh', 'h'))
-            dXP = self.buf('dxp%d' % g, Ms, 768)
-            lib.taco_gru256_seq_bwd(dD, self.P(sc + '/whg'), self.P(sc + '/whc'), R, U, C, Hh, dXP,
-                                    self.xchg(N), self.err, N, S, st)
-            self.flush_side()
-            self.gemm_dw(gin, dXP, self.G(sc + '/wx'), Ms, 256, 768)
-            self.colsum(dXP, self.G(sc + '/bias'), Ms, 768)
-            self.gemm_dw_shift(Hh, dXP, self.G(sc + '/whg'), Ms, S, 256, 512, 256, 768, 512)
-            self.gemm_dw(RH, dXP[:, 512:], self.G(sc + '/whc'), Ms, 256, 256, ldx=256, lddy=768, ldw=256)
-            self.gemm_dx(dXP, self.P(sc + '/wx'), dD, Ms, 256, 768, acc=1)     # dD_{g-1} = dD_g (residual) + dXP.Wx^T
-        dY = dD
-        dHC = b['dHC']
-        self.dense_bwd(b['HC'], dY, 'concat_projection', Ms, 512, 256, dx=dHC)
-        # attention recurrence
-        for k in ('dQ', 'dKEYS', 'dMEM', 'dVPART'):
-            b[k].zero_()
-        lib.taco_attn_rnn_bwd(self._attn_ptrs, self._attn_dims, st)
-        self.flush_side()
+            self.gemm_dw(gin, dxp[g], self.G(sc + '/wx'), Ms, 256, 768)
+            self.colsum(dxp[g], self.G(sc + '/bias'), Ms, 768)
+            self.gemm_dw_shift(b['g%d_h' % g], dxp[g], self.G(sc + '/whg'), Ms, S, 256, 512, 256, 768, 512)
+            self.gemm_dw(b['g%d_rh' % g], dxp[g][:, 512:], self.G(sc + '/whc'), Ms, 256, 256, ldx=256, lddy=768, ldw=256)
+        self.gemm_dw(b['HC'], dY, self.G('concat_projection/kernel'), Ms, 512, 256)
+        self.colsum(dY, self.G('concat_projection/bias'), Ms, 256)
         HC, dXPa, dP2, dP1, dQ = b['HC'], b['dXPa'], b['dP2'], b['dP1'], b['dQ']
         self.gemm_dw(b['P2'], dXPa, self.G('attention_gru/wx'), Ms, 128, 768)
         self.colsum(dXPa, self.G('attention_gru/bias'), Ms, 768)
