@@ -232,3 +232,40 @@ def test_empty_and_invalid_arguments_are_rejected():
         lib.taco_conv_gemm_fwd(x, x, None, x, 16, 16, 8, 8, 1, 0, 6, 8, 8, 0, 0, stream())     # ld not a multiple of 4
     with pytest.raises(RuntimeError, match='-22'):
         lib.taco_gru128_seq_fwd(None, 768, x, x, x, x, None, x, 256, x, 1, 1, 2, stream())     # null xp
+
+
+def test_train_py_end_to_end_with_feeder(tmp_path, monkeypatch):
+    """The drop-in flow of the reference's train.py: metadata + .npy files -> DataFeeder thread -> create_model /
+    initialize / add_loss / add_optimizer -> step loop with the reference's log line; loss must be finite and fall."""
+    import json
+    import sys
+    rng = np.random.RandomState(0)
+    lines = []
+    for i in range(12):
+        T = 23 + 3 * (i % 5)
+        paths = []
+        for kind, shape in (('spec', (T, 1025)), ('mel', (T, 80)), ('wav', (T * 250,))):
+            p = str(tmp_path / ('%s-%d.npy' % (kind, i)))
+            np.save(p, rng.rand(*shape).astype(np.float32))
+            paths.append(p)
+        lines.append(repr(paths + ['{%s}' % ' '.join('<sym%d>' % rng.randint(0, 7000) for _ in range(4 + i % 7)), i % 3]))
+    meta = tmp_path / 'toy_id_num_3.txt'
+    meta.write_text('\n'.join(lines) + '\n', encoding='utf-8')
+    (tmp_path / 'train_npy_data_dict.json').write_text(json.dumps({'TOY': str(meta)}))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(sys, 'argv', ['train.py', '--base_dir', str(tmp_path / 'logs'), '--train_data', 'TOY', '--description', 'toy',
+                                      '--hparams', 'batch_size=4,outputs_per_step=5,decay_learning_rate=false,initial_learning_rate=0.001',
+                                      '--max_steps', '12', '--checkpoint_interval', '5'])
+    import importlib
+    import hparams as H
+    importlib.reload(H)
+    import train
+    importlib.reload(train)
+    train.main()
+    log = (tmp_path / 'logs' / 'logs-tacotron-toy' / 'train.log').read_text()
+    losses = [float(l.split('loss=')[1].split(',')[0]) for l in log.splitlines() if 'avg_sec/step' in l]
+    assert len(losses) >= 12 and all(np.isfinite(losses))
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])
+    assert 'multi-speaker' in log and 'Saving checkpoint to:' in log
+    assert (tmp_path / 'logs' / 'logs-tacotron-toy' / 'model.ckpt-5').exists()
+    importlib.reload(H)
