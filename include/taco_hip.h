@@ -100,6 +100,9 @@ int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int
  * state passes through HC (forward) and the DHCARRY / DCTXCARRY slots (backward)); whole sequence: s0 = 0, s1 = S */
 int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stream);
+/* free-running inference decoder (reference models/helpers.py:7-38 TacoTestHelper, models/tacotron.py:86-94):
+ * ptrs indexed by enum TacoInferPtr (all required), dims = {N, S = steps to run, Ti, r, num_mels} */
+int taco_decoder_infer(const void* const* ptrs, const int* dims, hipStream_t stream);
 /* persistent-cluster path of the attention recurrence: shape support (1/0) and granule scratch size in 8-byte slots */
 int taco_attn_cluster_supported(int N, int Ti);
 int taco_attn_cluster_xchg_slots(int N, int Ti);
@@ -161,6 +164,24 @@ enum TacoAttnPtr {
     TACO_AP_DE,        /* cluster bwd: out, softmax-input gradients de_s[t]           [N,S,Ti] */
     TACO_AP_DCTXS,     /* cluster bwd: out, total context gradients per step          [N,S,256] */
     TACO_AP_COUNT
+};
+
+/* pointer-table slots of taco_decoder_infer (fp32 device pointers; weights as in the flat parameter layout) */
+enum TacoInferPtr {
+    TACO_IP_W1 = 0, TACO_IP_B1,      /* decoder_prenet dense_1 kernel [num_mels+256,256] (frame rows first), bias */
+    TACO_IP_W2, TACO_IP_B2,          /* decoder_prenet dense_2 */
+    TACO_IP_WX, TACO_IP_WHG, TACO_IP_WHC, TACO_IP_BG,       /* attention GRU (as TacoAttnPtr) */
+    TACO_IP_WQ, TACO_IP_V, TACO_IP_KEYS, TACO_IP_MEM, TACO_IP_ZEROS,
+    TACO_IP_WP, TACO_IP_BP,          /* concat projection [512,256] */
+    TACO_IP_G1WX, TACO_IP_G1B, TACO_IP_G1WHG, TACO_IP_G1WHC,  /* decoder GRU 1: wx [256,768], bias [768], whg, whc */
+    TACO_IP_G2WX, TACO_IP_G2B, TACO_IP_G2WHG, TACO_IP_G2WHC,
+    TACO_IP_WO, TACO_IP_BO,          /* output projection [256, num_mels*r] */
+    TACO_IP_HC,                      /* out: [h_s | ctx_s]                    [N,S,512] */
+    TACO_IP_ALIGN,                   /* out: alignments                       [N,S,Ti] */
+    TACO_IP_OUT,                     /* out: decoder outputs                  [N,S,num_mels*r] */
+    TACO_IP_H1, TACO_IP_H2,          /* scratch: GRU states, ping-pong        [2,N,256] each */
+    TACO_IP_TMP,                     /* scratch                               [10,N,256] */
+    TACO_IP_COUNT
 };
 
 #ifdef __cplusplus

@@ -60,6 +60,10 @@ class Tacotron():
             self._set_batch(*feeds)
             if is_training or mel_targets is not None:
                 self._forward()
+            else:      # synthesis (synthesizer.py:14-34): free-running decoder, batch norm on the moving statistics
+                e, st = self.engine, self._static
+                e.infer(st[0], st[1], st[4], max_iters=hp.max_iters)
+                self.mel_outputs, self.linear_outputs, self.alignments = e.mel_outputs, e.linear_outputs, e.alignments
         self.inputs, self.input_lengths = inputs, input_lengths
         self.identities, self.mel_targets, self.linear_targets = identities, mel_targets, linear_targets
         r = hp.outputs_per_step

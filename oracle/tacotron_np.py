@@ -292,6 +292,50 @@ def decoder_train(enc_out, mel_targets, P, r, num_mels=80):
     return outs, aligns
 
 
+def decoder_infer(enc_out, P, r, max_iters, num_mels=80):
+    """Free-running decode: models/helpers.py:7-38 (TacoTestHelper feeds the LAST of the r predicted frames back, stops
+    when a whole r-frame output is exactly zero -- checked after the step -- or at max_iters), tacotron.py:86-94."""
+    N, Ti, _ = enc_out.shape
+    keys = enc_out @ P['attention/memory_layer/kernel']
+    v = P['attention/attention_v']
+    h_att = np.zeros((N, 256)); ctx = np.zeros((N, 256)); g1 = np.zeros((N, 256)); g2 = np.zeros((N, 256))
+    frame = np.zeros((N, num_mels))
+    outs, aligns = [], []
+    finished = np.zeros(N, dtype=bool)
+    for s in range(max_iters):
+        p = prenet(np.concatenate([frame, ctx], -1), P, 'decoder_prenet')
+        h_att = gru_cell(p, h_att, P, 'attention_gru')
+        q = h_att @ P['attention/query_layer/kernel']
+        score = np.einsum('ntd,d->nt', np.tanh(keys + q[:, None, :]), v)
+        a = softmax(score, axis=1)
+        ctx = np.einsum('nt,ntd->nd', a, enc_out)
+        y = np.concatenate([h_att, ctx], -1) @ P['concat_projection/kernel'] + P['concat_projection/bias']
+        g1 = gru_cell(y, g1, P, 'decoder_gru_1'); d1 = y + g1
+        g2 = gru_cell(d1, g2, P, 'decoder_gru_2'); d2 = d1 + g2
+        o = d2 @ P['output_projection/kernel'] + P['output_projection/bias']
+        outs.append(o); aligns.append(a)
+        finished |= np.all(o == 0.0, axis=1)
+        if finished.all():
+            break
+        frame = o[:, -num_mels:]
+    return np.stack(outs, 1), np.stack(aligns, 2)
+
+
+def forward_infer(P, inputs, input_lengths, identities=None, id_num=0, r=5, max_iters=2000, num_mels=80):
+    """models/tacotron.py:35-104 with linear_targets=None: batch norm uses the moving statistics."""
+    emb = P['embedding'][inputs]
+    if identities is not None and id_num > 1:
+        eid = P['embedding_id'][identities][:, None, :]
+        emb = np.concatenate([emb, np.tile(eid, (1, inputs.shape[1], 1))], axis=2)
+    pre = prenet(emb, P, 'prenet')
+    enc = cbhg(pre, input_lengths, P, 'encoder_cbhg', 16, False, None)
+    dec, aligns = decoder_infer(enc, P, r, max_iters, num_mels)
+    mel_out = dec.reshape(inputs.shape[0], -1, num_mels)
+    post = cbhg(mel_out, None, P, 'post_cbhg', 8, False, None)
+    lin_out = dense(post, P['linear/kernel'], P['linear/bias'])
+    return dict(mel_outputs=mel_out, linear_outputs=lin_out, alignments=aligns, encoder_outputs=enc)
+
+
 def forward(P, inputs, input_lengths, mel_targets, identities=None, id_num=0, r=5,
             num_mels=80, training=True):
     """models/tacotron.py:35-104.  Returns dict(mel_outputs, linear_outputs, alignments, bn_stats)."""

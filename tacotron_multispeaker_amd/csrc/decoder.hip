@@ -522,3 +522,87 @@ extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipSt
     if (dims[3] != 0 || dims[4] != S) return TACO_EINVAL;
     return attn_rnn_bwd_steps(ptrs, dims, st);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Free-running inference decoder (reference models/helpers.py:7-38 TacoTestHelper + tacotron.py:86-94): the last of the r
+// predicted frames is fed back, so nothing can be hoisted; one launch per dependent stage (13 per step).  The reference
+// stops when a whole r-frame output is EXACTLY zero (never in practice) or at max_iters; this runs `S` steps.
+// ptrs indexed by enum TacoInferPtr, dims = {N, S, Ti, r, num_mels}.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int taco_decoder_infer(const void* const* ptrs, const int* dims, hipStream_t st) {
+    if (!ptrs || !dims) return TACO_EINVAL;
+    const int N = dims[0], S = dims[1], Ti = dims[2], r = dims[3], nm = dims[4];
+    if (N <= 0 || S <= 0 || Ti <= 0 || r <= 0 || nm <= 0 || (nm & 3)) return TACO_EINVAL;
+    for (int i = 0; i < TACO_IP_COUNT; ++i) if (!ptrs[i]) return TACO_EINVAL;
+    auto F = [&](int i) { return (const float*)ptrs[i]; };
+    auto G = [&](int i) { return (float*)const_cast<void*>(ptrs[i]); };
+    const float* zeros = F(TACO_IP_ZEROS);
+    const int no = nm * r;
+    const size_t smem = (((Ti + 3) & ~3) + 256) * sizeof(float);
+    auto gru = [&](const float* x, int ldx, int wx, int b, int whg, int whc, const float* hprev, int ldprev, float* R, float* U,
+                   float* C, float* RH, float* Hn, int ldh, float* D) {
+        Skinny k{};
+        k.A0 = x; k.lda0 = ldx; k.K0 = 256; k.B0 = F(wx); k.ldb0 = 768; k.A1 = hprev; k.lda1 = ldprev; k.K1 = 256; k.B1 = F(whg); k.ldb1 = 512;
+        k.M = N; k.N = 512; k.mode = M_GRU_GATES; k.Hd = 256; k.p[1] = F(b); k.p[2] = hprev; k.ld[2] = ldprev;
+        k.o[0] = R; k.ldo[0] = 256; k.o[1] = U; k.ldo[1] = 256; k.o[2] = RH; k.ldo[2] = 256;
+        launch_skinny(k, st);
+        k = Skinny{};
+        k.A0 = x; k.lda0 = ldx; k.K0 = 256; k.B0 = F(wx) + 512; k.ldb0 = 768; k.A1 = RH; k.lda1 = 256; k.K1 = 256; k.B1 = F(whc); k.ldb1 = 256;
+        k.M = N; k.N = 256; k.mode = M_GRU_CAND; k.Hd = 256; k.p[1] = F(b) + 512; k.p[2] = hprev; k.ld[2] = ldprev; k.p[3] = U; k.ld[3] = 256;
+        k.p[4] = x; k.ld[4] = ldx;
+        k.o[0] = C; k.ldo[0] = 256; k.o[1] = Hn; k.ldo[1] = ldh; k.o[2] = D; k.ldo[2] = 256;
+        launch_skinny(k, st);
+    };
+    float* H1 = G(TACO_IP_H1);            // [2][N,256] ping-pong states
+    float* H2 = G(TACO_IP_H2);
+    float* T = G(TACO_IP_TMP);            // [10][N,256] step scratch: p1, p2(128), r, u, c, rh, q, y, d1, d2
+    float *p1 = T, *p2 = T + (long)N * 256, *R = T + 2L * N * 256, *U = T + 3L * N * 256, *C = T + 4L * N * 256,
+          *RH = T + 5L * N * 256, *Q = T + 6L * N * 256, *Y = T + 7L * N * 256, *D1 = T + 8L * N * 256, *D2 = T + 9L * N * 256;
+    for (int s = 0; s < S; ++s) {
+        const bool first = s == 0;
+        float* hc_s = G(TACO_IP_HC) + (long)s * 512;                 // [N] rows, ld S*512
+        const float* hprev = first ? zeros : hc_s - 512;
+        const float* ctxprev = first ? zeros : hc_s - 512 + 256;
+        const int ldprev = first ? 256 : S * 512;
+        const float* frame = first ? zeros : F(TACO_IP_OUT) + (long)(s - 1) * no + (long)(r - 1) * nm;
+        const int ldf = first ? 256 : S * no;
+        Skinny k{};
+        k.A0 = frame; k.lda0 = ldf; k.K0 = nm; k.B0 = F(TACO_IP_W1); k.ldb0 = 256;
+        k.A1 = ctxprev; k.lda1 = ldprev; k.K1 = 256; k.B1 = F(TACO_IP_W1) + (long)nm * 256; k.ldb1 = 256;
+        k.M = N; k.N = 256; k.mode = M_BIAS_RELU; k.p[0] = F(TACO_IP_B1); k.o[0] = p1; k.ldo[0] = 256;
+        launch_skinny(k, st);
+        k = Skinny{}; k.A0 = p1; k.lda0 = 256; k.K0 = 256; k.B0 = F(TACO_IP_W2); k.ldb0 = 128;
+        k.M = N; k.N = 128; k.mode = M_BIAS_RELU; k.p[0] = F(TACO_IP_B2); k.o[0] = p2; k.ldo[0] = 128;
+        launch_skinny(k, st);
+        k = Skinny{}; k.A0 = p2; k.lda0 = 128; k.K0 = 128; k.B0 = F(TACO_IP_WX); k.ldb0 = 768;
+        k.A1 = hprev; k.lda1 = ldprev; k.K1 = 256; k.B1 = F(TACO_IP_WHG); k.ldb1 = 512;
+        k.M = N; k.N = 512; k.mode = M_GRU_GATES; k.Hd = 256; k.p[1] = F(TACO_IP_BG); k.p[2] = hprev; k.ld[2] = ldprev;
+        k.o[0] = R; k.ldo[0] = 256; k.o[1] = U; k.ldo[1] = 256; k.o[2] = RH; k.ldo[2] = 256;
+        launch_skinny(k, st);
+        k = Skinny{}; k.A0 = p2; k.lda0 = 128; k.K0 = 128; k.B0 = F(TACO_IP_WX) + 512; k.ldb0 = 768;
+        k.A1 = RH; k.lda1 = 256; k.K1 = 256; k.B1 = F(TACO_IP_WHC); k.ldb1 = 256;
+        k.M = N; k.N = 256; k.mode = M_GRU_CAND; k.Hd = 256; k.p[1] = F(TACO_IP_BG) + 512;
+        k.p[2] = hprev; k.ld[2] = ldprev; k.p[3] = U; k.ld[3] = 256;
+        k.o[0] = C; k.ldo[0] = 256; k.o[1] = hc_s; k.ldo[1] = S * 512;
+        launch_skinny(k, st);
+        k = Skinny{}; k.A0 = hc_s; k.lda0 = S * 512; k.K0 = 256; k.B0 = F(TACO_IP_WQ); k.ldb0 = 256;
+        k.M = N; k.N = 256; k.mode = M_LINEAR; k.o[0] = Q; k.ldo[0] = 256;
+        launch_skinny(k, st);
+        float* al = G(TACO_IP_ALIGN) + (long)s * Ti;
+        hipLaunchKernelGGL(attn_scores_k, dim3(N, cdiv(Ti, 16)), dim3(256), 0, st, F(TACO_IP_KEYS), Q, 256, F(TACO_IP_V), al, S * Ti, Ti);
+        hipLaunchKernelGGL(attn_softmax_ctx_k, dim3(N, 4), dim3(256), smem, st, al, S * Ti, F(TACO_IP_MEM), hc_s + 256, S * 512, Ti);
+        k = Skinny{}; k.A0 = hc_s; k.lda0 = S * 512; k.K0 = 512; k.B0 = F(TACO_IP_WP); k.ldb0 = 256;
+        k.M = N; k.N = 256; k.mode = M_LINEAR; k.p[0] = F(TACO_IP_BP); k.o[0] = Y; k.ldo[0] = 256;
+        launch_skinny(k, st);
+        float* h1n = H1 + (long)(s & 1) * N * 256;
+        const float* h1p = first ? zeros : H1 + (long)((s - 1) & 1) * N * 256;
+        gru(Y, 256, TACO_IP_G1WX, TACO_IP_G1B, TACO_IP_G1WHG, TACO_IP_G1WHC, h1p, 256, R, U, C, RH, h1n, 256, D1);
+        float* h2n = H2 + (long)(s & 1) * N * 256;
+        const float* h2p = first ? zeros : H2 + (long)((s - 1) & 1) * N * 256;
+        gru(D1, 256, TACO_IP_G2WX, TACO_IP_G2B, TACO_IP_G2WHG, TACO_IP_G2WHC, h2p, 256, R, U, C, RH, h2n, 256, D2);
+        k = Skinny{}; k.A0 = D2; k.lda0 = 256; k.K0 = 256; k.B0 = F(TACO_IP_WO); k.ldb0 = no;
+        k.M = N; k.N = no; k.mode = M_LINEAR; k.p[0] = F(TACO_IP_BO); k.o[0] = G(TACO_IP_OUT) + (long)s * no; k.ldo[0] = S * no;
+        launch_skinny(k, st);
+    }
+    TACO_RETURN_LAST();
+}

@@ -367,6 +367,51 @@ class Engine:
         dll = lib.load()
         return max(dll.taco_attn_cluster_xchg_slots(N, Ti), dll.taco_attn_cluster_bwd_xchg_slots(N, Ti))
 
+    _IP = ['W1', 'B1', 'W2', 'B2', 'WX', 'WHG', 'WHC', 'BG', 'WQ', 'V', 'KEYS', 'MEM', 'ZEROS', 'WP', 'BP', 'G1WX', 'G1B', 'G1WHG',
+           'G1WHC', 'G2WX', 'G2B', 'G2WHG', 'G2WHC', 'WO', 'BO', 'HC', 'ALIGN', 'OUT', 'H1', 'H2', 'TMP']
+
+    def infer(self, inputs, input_lengths, identities=None, steps=None, max_iters=2000):
+        """Free-running synthesis (reference models/tacotron.py:18-104 with linear_targets=None, models/helpers.py:7-38):
+        batch norm in inference mode, the last predicted frame fed back, `steps` decoder steps (default max_iters: the
+        reference's exact-zero stop token never fires in practice).  Returns (mel [N,S*r,80], linear, alignments [N,Ti,S])."""
+        L, st = self.L, self.st
+        N, Ti = inputs.shape
+        S = int(steps if steps is not None else max_iters)
+        r, nm = self.r, self.nm
+        self._dpos = 0
+        E = L.Et + L.Es
+        Me = N * Ti
+        X0 = self.buf('emb', Me, E)
+        lib.taco_embed_gather_fwd(inputs, identities if L.Es else None, self.P('embedding'),
+                                  self.P('embedding_id') if L.Es else None, X0, N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
+        A1, A2 = self.buf('enc_p1', Me, 256), self.buf('enc_p2', Me, 128)
+        self.dense_fwd(X0, 'prenet/dense_1', A1, Me, E, 256, ACT_RELU)
+        self.dense_fwd(A1, 'prenet/dense_2', A2, Me, 256, 128, ACT_RELU)
+        ENC = self.cbhg_fwd('encoder_cbhg', A2, N, Ti, 128, 16, (128, 128), input_lengths, False)
+        KEYS = self.buf('keys', Me, 256)
+        self.gemm(ENC, self.P('attention/memory_layer/kernel'), None, KEYS, Me, 256, 256)
+        z = self.buf('zeros', max(N, 32) * 256)
+        P = self.P
+        t = {'W1': P('decoder_prenet/dense_1/kernel'), 'B1': P('decoder_prenet/dense_1/bias'), 'W2': P('decoder_prenet/dense_2/kernel'),
+             'B2': P('decoder_prenet/dense_2/bias'), 'WX': P('attention_gru/wx'), 'WHG': P('attention_gru/whg'), 'WHC': P('attention_gru/whc'),
+             'BG': P('attention_gru/bias'), 'WQ': P('attention/query_layer/kernel'), 'V': P('attention/attention_v'), 'KEYS': KEYS, 'MEM': ENC,
+             'ZEROS': z, 'WP': P('concat_projection/kernel'), 'BP': P('concat_projection/bias'),
+             'G1WX': P('decoder_gru_1/wx'), 'G1B': P('decoder_gru_1/bias'), 'G1WHG': P('decoder_gru_1/whg'), 'G1WHC': P('decoder_gru_1/whc'),
+             'G2WX': P('decoder_gru_2/wx'), 'G2B': P('decoder_gru_2/bias'), 'G2WHG': P('decoder_gru_2/whg'), 'G2WHC': P('decoder_gru_2/whc'),
+             'WO': P('output_projection/kernel'), 'BO': P('output_projection/bias'),
+             'HC': self.buf('i_HC', N * S, 512), 'ALIGN': self.buf('i_ALIGN', N * S, Ti), 'OUT': self.buf('i_mel', N, S * r, nm),
+             'H1': self.buf('i_H1', 2, N, 256), 'H2': self.buf('i_H2', 2, N, 256), 'TMP': self.buf('i_TMP', 10, N, 256)}
+        arr = (ctypes.c_void_p * len(self._IP))(*[t[n].data_ptr() for n in self._IP])
+        lib.taco_decoder_infer(arr, (ctypes.c_int * 5)(N, S, Ti, r, nm), st)
+        MEL = t['OUT']
+        POST = self.cbhg_fwd('post_cbhg', MEL.view(N * S * r, nm), N, S * r, nm, 8, (256, nm), None, False)
+        LIN = self.buf('i_lin', N, S * r, self.nf)
+        self.gemm(POST, self.P('linear/kernel'), self.P('linear/bias'), LIN, N * S * r, 256, self.nf, ldw=L.ld_lin, ldy=self.nf)
+        self.mel_outputs, self.linear_outputs = MEL, LIN
+        self.alignments = t['ALIGN'].view(N, S, Ti).transpose(1, 2)
+        self.encoder_outputs = ENC.view(N, Ti, 256)
+        return MEL, LIN, self.alignments
+
     def _make_attn_ptrs(self, N, S, Ti):
         b = self.buf
         W1 = self.P('decoder_prenet/dense_1/kernel')

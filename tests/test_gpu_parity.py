@@ -269,3 +269,47 @@ def test_train_py_end_to_end_with_feeder(tmp_path, monkeypatch):
     assert 'multi-speaker' in log and 'Saving checkpoint to:' in log
     assert (tmp_path / 'logs' / 'logs-tacotron-toy' / 'model.ckpt-5').exists()
     importlib.reload(H)
+
+
+@pytest.mark.parametrize('cfg', [(2, 9, 7, 2, 0), (3, 14, 5, 5, 4), (1, 6, 9, 1, 0)])
+def test_free_running_inference_matches_oracle(cfg):
+    """Synthesis mode (linear_targets=None): batch norm on the moving statistics, last predicted frame fed back
+    (reference models/helpers.py:7-38, models/tacotron.py:86-94, synthesizer.py:14-34)."""
+    from oracle import tacotron_np as onp
+    from tacotron_multispeaker_amd.engine import Engine
+    N, Ti, S, r, idn = cfg
+    P = onp.init_params(seed=9, r=r, id_num=idn)
+    rng = np.random.RandomState(4)
+    for k in P:
+        if k.endswith('/moving_mean'):
+            P[k] = 0.2 * rng.standard_normal(P[k].shape)
+        if k.endswith('/moving_variance'):
+            P[k] = 0.5 + rng.uniform(0, 1, P[k].shape)
+        if k.endswith(('/bias', '/beta')):
+            P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+    b = onp.synth_batch(N, Ti, 10 * r, r, seed=5, id_num=idn)
+    ref = onp.forward_infer(P, b['inputs'], b['input_lengths'], b['identities'], idn, r, max_iters=S)
+    eng = Engine(id_num=idn, r=r, named_params=P)
+    i, l, _, _, ids = dev_batch(b, eng.dev)
+    mel, lin, al = eng.infer(i, l, ids, steps=S)
+    torch.cuda.synchronize()
+    assert mel.shape == (N, S * r, 80) and lin.shape == (N, S * r, 1025) and al.shape == (N, Ti, S)
+    assert rel(mel.cpu().numpy(), ref['mel_outputs']) < TOL
+    assert rel(lin.cpu().numpy(), ref['linear_outputs']) < TOL
+    assert rel(al.cpu().numpy(), ref['alignments']) < TOL
+
+
+def test_model_api_synthesis_mode():
+    """create_model('tacotron', hparams).initialize(inputs, input_lengths) -- the call synthesizer.py:26 makes."""
+    import importlib
+    import hparams as H
+    importlib.reload(H)
+    from models import create_model
+    H.hparams.parse('outputs_per_step=5,max_iters=4')
+    m = create_model('tacotron', H.hparams)
+    ids = np.array([[5, 9, 33, 1, 0, 0]], dtype=np.int32)
+    m.initialize(ids, np.array([4], dtype=np.int32))
+    assert tuple(m.mel_outputs.shape) == (1, 20, 80) and tuple(m.linear_outputs.shape) == (1, 20, 1025)
+    assert tuple(m.alignments.shape) == (1, 6, 4)
+    assert bool(torch.isfinite(m.linear_outputs).all())
+    importlib.reload(H)
