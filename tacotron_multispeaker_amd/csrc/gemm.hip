@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+constexpr int KPAD = 4;      // v1 kernels: k-contiguous LDS tiles are padded by 4 floats per row
 struct ConvGemm {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K;        // NN/NT: M rows, N output cols, K reduction per tap.  TN: M reduction rows, K x N output
@@ -41,7 +42,7 @@ __device__ __forceinline__ long rowmap(const ConvGemm& p, int m) {
 template <int BM, int BN, int BK, bool AKC, bool BKC>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
                                          f32x16 (&acc)[BM / 64][BN / 64], int wm, int wn, int lane) {
-    constexpr int MI = BM / 64, NI = BN / 64, LDK = BK + 4;
+    constexpr int MI = BM / 64, NI = BN / 64, LDK = BK + KPAD;
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
@@ -97,7 +98,7 @@ template <int ROWS, int BK>
 struct KC {
     static constexpr int NV = ROWS * BK / 4 / 256;
     static constexpr int TPR = BK / 4;
-    static constexpr int LDK = BK + 4;
+    static constexpr int LDK = BK + KPAD;
     __device__ static __forceinline__ int row(int tid, int v) { return (tid + v * 256) / TPR; }
     __device__ static __forceinline__ int c4(int tid, int v) { return (tid + v * 256) % TPR; }
     __device__ static __forceinline__ void store(float* s, int tid, const float4 (&r)[NV]) {
@@ -157,7 +158,7 @@ template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void conv_gemm_nn(ConvGemm p) {
     using TA = KC<BM, BK>;
     using TB = KS<BN, BK>;
-    __shared__ __attribute__((aligned(16))) float smem[2][BM * (BK + 4) + BK * BN];
+    __shared__ __attribute__((aligned(16))) float smem[2][BM * (BK + KPAD) + BK * BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.bank) by = gridDim.y - 1 - blockIdx.y;                         // bank: widest convs first
@@ -213,17 +214,197 @@ __global__ __launch_bounds__(256) void conv_gemm_nn(ConvGemm p) {
 
     gload(0);
     TA::store(smem[0], tid, ra);
-    TB::store(smem[0] + BM * (BK + 4), tid, rb);
+    TB::store(smem[0] + BM * (BK + KPAD), tid, rb);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         if (s + 1 < nsteps) gload(s + 1);
-        mma_tile<BM, BN, BK, true, false>(smem[cur], smem[cur] + BM * (BK + 4), acc, wm, wn, lane);
+        mma_tile<BM, BN, BK, true, false>(smem[cur], smem[cur] + BM * (BK + KPAD), acc, wm, wn, lane);
         if (s + 1 < nsteps) {
             TA::store(smem[cur ^ 1], tid, ra);
-            TB::store(smem[cur ^ 1] + BM * (BK + 4), tid, rb);
+            TB::store(smem[cur ^ 1] + BM * (BK + KPAD), tid, rb);
         }
         __syncthreads();
+    }
+    epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// =====================================================================================================
+// NN v2: K-loop with (almost) no VALU work.  rocprofv3 PMC on v1 showed SQ_VALU_MFMA_COEXEC_CYCLES == 0 and ~3.7 non-MFMA
+// VALU instructions per MFMA (address arithmetic, zero fills): on gfx950 every such instruction takes issue time away
+// from the fp32 MFMA stream of the SIMD, which capped v1 at ~65 % MFMA utilisation.  Here
+//   * tiles go global -> LDS with buffer_load_dwordx4 ... lds (no VGPR staging, no ds_write, no zero-fill moves);
+//   * per-lane byte offsets are computed once per conv tap; the K walk only bumps the scalar soffset;
+//   * masked elements (conv padding rows, ragged edges) use an out-of-range voffset -> the buffer unit returns 0;
+//   * LDS stages are unrolled statically so every ds_read address is a loop-invariant VGPR + immediate.
+// A tile [BM][32] k-contiguous, unpadded, 16-byte chunks XOR-swizzled by (row >> 1) & 7 (applied on the global side: each
+// lane picks its source chunk, the LDS side of the instruction is lane-contiguous).  B tile [32][BN] k-strided.
+// Requires operand byte sizes < 2 GiB (32-bit buffer offsets); the launcher falls back to v1 otherwise.
+// =====================================================================================================
+typedef __attribute__((address_space(3))) void* lptr_t;
+#define TACO_OOB 0x80000000u
+
+// (the resource type is only named inside __device__ helpers: a __global__ body that declares it loses its host stub)
+__device__ __forceinline__ void buf_load_lds16(const void* base, float* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000),
+                                             (lptr_t)lds, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int BK>
+struct MmaSw {
+    static constexpr int MI = BM / 64, NI = BN / 64, KK = BK / 8;
+    int aaddr[MI][KK];     // float index of this lane's A chunk for kk = 0..KK-1
+    int baddr[NI];         // float index of this lane's B column at k = 4h
+    __device__ __forceinline__ void init(int wm, int wn, int lane) {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * (BM / 2) + mi * 32 + i;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) aaddr[mi][kk] = row * BK + (((kk * 2 + h) ^ ((row / (64 / BK)) & (BK / 4 - 1))) << 2);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) baddr[ni] = 4 * h * BN + wn * (BN / 2) + ni * 32 + i;
+    }
+    __device__ __forceinline__ void run(const float* __restrict__ As, const float* __restrict__ Bs, f32x16 (&acc)[MI][NI]) const {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            float a[MI][4], b[NI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const float4 v = *reinterpret_cast<const float4*>(&As[aaddr[mi][kk]]);
+                a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[ni][q] = Bs[baddr[ni] + (kk * 8 + q) * BN];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][q], b[ni][q], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int BM, int BN, int BK, int STAGES, bool KTAIL>
+__global__ __launch_bounds__(256) void conv_gemm_nn2(ConvGemm p) {
+    constexpr int ASZ = BM * BK, BSZ = BK * BN, SSZ = ASZ + BSZ;
+    constexpr int CPR = BK / 4;             // 16-byte chunks per A row
+    constexpr int RPI = 64 / CPR;           // A rows per wave-instruction (1 KiB)
+    constexpr int NVA = BM / (RPI * 4);
+    constexpr int RB = 256 / BN;            // B k rows per wave-instruction
+    constexpr int NVB = BK / (RB * 4);
+    constexpr int LPR = BN / 4;             // lanes per B k-row
+    constexpr int LPS = NVA + NVB;          // loads per step per wave
+    static_assert(NVA >= 1 && NVB >= 1 && (STAGES == 2 || STAGES == 3), "tile config");
+    __shared__ __attribute__((aligned(16))) float smem[STAGES][SSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.bank) by = gridDim.y - 1 - blockIdx.y;                         // bank: widest convs first
+    else xcd_tile(bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
+
+    int kw = p.kw_lo, ldb = p.ldb, nloc0 = n0, nlim = p.N;
+    const float* Bb = p.B;
+    if (p.bank) {
+        kw = 1 + n0 / p.cpb;
+        Bb = p.B + (long)p.K * p.cpb * ((kw - 1) * kw / 2);
+        ldb = p.cpb;
+        nloc0 = n0 - (kw - 1) * p.cpb;
+        nlim = p.cpb;
+    }
+    const int pl = (kw - 1) / 2;
+    const int ksteps = (p.K + BK - 1) / BK;
+    const int nsteps = kw * ksteps;
+
+    // per-lane constants
+    int tpos[NVA], acol[NVA];
+    unsigned arow[NVA];
+    bool arok[NVA];
+#pragma unroll
+    for (int v = 0; v < NVA; ++v) {
+        const int r = (v * 4 + wave) * RPI + lane / CPR;
+        tpos[v] = (m0 + r) % p.T;
+        arow[v] = (unsigned)rowmap(p, m0 + r);
+        arok[v] = m0 + r < p.M;
+        acol[v] = ((lane % CPR) ^ ((r / (64 / BK)) & (CPR - 1))) * 4;    // k offset (floats) of the chunk this lane fetches
+    }
+    unsigned voa[NVA], voa_last[NVA], vob[NVB], vob_last[NVB];
+    const int klast = (ksteps - 1) * BK;
+#pragma unroll
+    for (int v = 0; v < NVB; ++v) {
+        const int kl = (v * 4 + wave) * RB + lane / LPR;
+        const int n = nloc0 + (lane % LPR) * 4;
+        vob[v] = n < nlim ? (unsigned)(kl * ldb + n) * 4u : TACO_OOB;
+        vob_last[v] = klast + kl < p.K ? vob[v] : TACO_OOB;
+    }
+    auto tap_offsets = [&](int j) {
+        const int shift = j - pl;
+#pragma unroll
+        for (int v = 0; v < NVA; ++v) {
+            const bool ok = arok[v] && (unsigned)(tpos[v] + shift) < (unsigned)p.T;
+            voa[v] = ok ? ((arow[v] + shift) * (unsigned)p.lda + acol[v]) * 4u : TACO_OOB;
+            voa_last[v] = klast + acol[v] < p.K ? voa[v] : TACO_OOB;
+        }
+    };
+    // next tile to issue: tap i_j, k chunk i_kc; scalar byte offsets soa (A) / sob (B) follow them
+    int i_j = 0, i_kc = 0, soa = 0, sob = 0, issued = 0;
+    const int bstep = BK * ldb * 4, btap = p.K * ldb * 4;
+    auto issue = [&](float* stage) {
+        if (i_kc == 0) tap_offsets(i_j);
+        const bool last = KTAIL && i_kc == ksteps - 1;
+#pragma unroll
+        for (int v = 0; v < NVA; ++v)
+            buf_load_lds16(p.A, stage + (v * 4 + wave) * RPI * BK, last ? voa_last[v] : voa[v], soa);
+#pragma unroll
+        for (int v = 0; v < NVB; ++v)
+            buf_load_lds16(Bb, stage + ASZ + (v * 4 + wave) * RB * BN, last ? vob_last[v] : vob[v], sob);
+        ++i_kc; ++issued; soa += BK * 4; sob += bstep;
+        if (i_kc == ksteps) { i_kc = 0; ++i_j; soa = 0; sob = __builtin_amdgcn_readfirstlane(i_j * btap); }
+    };
+
+    f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < BN / 64; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    MmaSw<BM, BN, BK> mm;
+    mm.init(wm, wn, lane);
+
+    // Ring of STAGES static LDS stages, tiles s+1 .. s+STAGES-1 in flight while tile s is multiplied.
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nsteps) issue(smem[t]);
+    if (STAGES == 3 && nsteps >= 2) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+    __syncthreads();
+    const int ngroups = nsteps / STAGES;
+    for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+        for (int u = 0; u < STAGES; ++u) {
+            const bool more = issued < nsteps;
+            if (more) issue(smem[(u + STAGES - 1) % STAGES]);
+            mm.run(smem[u], smem[u] + ASZ, acc);
+            if (STAGES == 3 && more) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __syncthreads();
+        }
+    }
+    const int rem = nsteps - ngroups * STAGES;
+    if (rem >= 1) {
+        mm.run(smem[0], smem[0] + ASZ, acc);
+        if (STAGES == 3 && rem == 2) {
+            wait_vmcnt<0>();
+            __syncthreads();
+            mm.run(smem[1], smem[1] + ASZ, acc);
+        }
     }
     epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -236,7 +417,7 @@ template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
     using TA = KC<BM, BK>;
     using TB = KC<BN, BK>;
-    __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * (BK + 4)];
+    __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * (BK + KPAD)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     int bx, by;
     xcd_tile(bx, by);
@@ -295,15 +476,15 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
 
     gload();
     TA::store(smem[0], tid, ra);
-    TB::store(smem[0] + BM * (BK + 4), tid, rb);
+    TB::store(smem[0] + BM * (BK + KPAD), tid, rb);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         if (s + 1 < nsteps) gload();
-        mma_tile<BM, BN, BK, true, true>(smem[cur], smem[cur] + BM * (BK + 4), acc, wm, wn, lane);
+        mma_tile<BM, BN, BK, true, true>(smem[cur], smem[cur] + BM * (BK + KPAD), acc, wm, wn, lane);
         if (s + 1 < nsteps) {
             TA::store(smem[cur ^ 1], tid, ra);
-            TB::store(smem[cur ^ 1] + BM * (BK + 4), tid, rb);
+            TB::store(smem[cur ^ 1] + BM * (BK + KPAD), tid, rb);
         }
         __syncthreads();
     }
@@ -429,6 +610,59 @@ static int check_common(const ConvGemm& p) {
     return TACO_OK;
 }
 
+// ---- NN dispatch ---------------------------------------------------------------------------------------------------
+// v2 (buffer_load ... lds, VALU-free K loop) whenever every operand offset fits 31 bits; otherwise the generic v1 kernel.
+// Tile configurations measured with scripts/gemm_bench.hip on MI355X (us, post-net shapes at C2):
+//   64x64x32, 3 stages : best general choice (3 WGs/CU, a lone workgroup still hides the load latency)
+//   64x64x32, 2 stages : short reductions (<= 16 K-steps: prologue of the deeper ring is not amortised)
+//   64x64x16, 3 stages : Cin with a large remainder mod 32 (post-net bank, Cin = 80)
+//   128x128x16, 3 stages: >= 2048 big tiles (143 TFLOP/s on a plain 8192 x 8192 x 2048 GEMM)
+// TACO_NN2_TILE=<0..3> forces a configuration, TACO_NN_V1=1 forces the v1 kernel (tuning aids).
+static long max_phys_row(const ConvGemm& p) {
+    const long m = p.M - 1;
+    return p.rb_len ? (m / p.rb_len) * p.rb_stride + p.rb_off + (m % p.rb_len) : m;
+}
+static bool fits31(const ConvGemm& p) {
+    const long abytes = (max_phys_row(p) + 1 + p.kw_hi) * (long)p.lda * 4;
+    long wrows = 0;
+    for (int k = p.kw_lo; k <= p.kw_hi; ++k) wrows += (long)k * p.K;
+    if (!p.bank) wrows = (long)p.kw_hi * p.K;
+    const long bbytes = (wrows + 64) * (long)p.ldb * 4;
+    return abytes < (1L << 31) && bbytes < (1L << 31);
+}
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+#define NN2_LAUNCH(BM_, BN_, BK_, ST_) do { dim3 g2(cdiv(p.M, BM_), cdiv(p.N, BN_)); \
+        if (p.K % BK_) hipLaunchKernelGGL((conv_gemm_nn2<BM_, BN_, BK_, ST_, true>), g2, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((conv_gemm_nn2<BM_, BN_, BK_, ST_, false>), g2, dim3(256), 0, stream, p); } while (0)
+
+static void launch_nn(const ConvGemm& p, hipStream_t stream) {
+    static const int force_v1 = env_int("TACO_NN_V1", 0), force_cfg = env_int("TACO_NN2_TILE", -1);
+    const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+    if (force_v1 || !fits31(p)) {
+        if (use128(tiles128, p.N)) {
+            dim3 g(cdiv(p.M, 128), cdiv(p.N, 128));
+            hipLaunchKernelGGL((conv_gemm_nn<128, 128, 16>), g, dim3(256), 0, stream, p);
+        } else {
+            dim3 g(cdiv(p.M, 64), cdiv(p.N, 64));
+            hipLaunchKernelGGL((conv_gemm_nn<64, 64, 32>), g, dim3(256), 0, stream, p);
+        }
+        return;
+    }
+    int cfg = force_cfg;
+    if (cfg < 0) {
+        const int k32 = cdiv(p.K, 32) * 32;
+        if (tiles128 >= 2048) cfg = 3;
+        else if ((k32 - p.K) * 8 > p.K) cfg = 2;
+        else if (p.kw_hi * (k32 / 32) <= 16) cfg = 1;
+        else cfg = 0;
+    }
+    if (cfg == 1) NN2_LAUNCH(64, 64, 32, 2);
+    else if (cfg == 2) NN2_LAUNCH(64, 64, 16, 3);
+    else if (cfg == 3) NN2_LAUNCH(128, 128, 16, 3);
+    else NN2_LAUNCH(64, 64, 32, 3);
+}
+
 extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin,
                                   int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate,
                                   hipStream_t stream) {
@@ -440,14 +674,7 @@ extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* b
     else { p.bank = 0; p.cpb = 0; p.N = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
     if (int e = check_common(p)) return e;
     if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
-    const long tiles128 = (long)cdiv(M, 128) * cdiv(p.N, 128);
-    if (use128(tiles128, p.N)) {
-        dim3 g(cdiv(M, 128), cdiv(p.N, 128));
-        hipLaunchKernelGGL((conv_gemm_nn<128, 128, 16>), g, dim3(256), 0, stream, p);
-    } else {
-        dim3 g(cdiv(M, 64), cdiv(p.N, 64));
-        hipLaunchKernelGGL((conv_gemm_nn<64, 64, 32>), g, dim3(256), 0, stream, p);
-    }
+    launch_nn(p, stream);
     TACO_RETURN_LAST();
 }
 
@@ -538,8 +765,7 @@ extern "C" int taco_dense_rows_fwd(const float* X, const float* W, const float* 
     if (ch <= 0 || s0 < 0 || s1 > S) return TACO_EINVAL;
     if (int e = check_common(p)) return e;
     if (p.K & 3) return TACO_EINVAL;
-    dim3 g(cdiv(M, 64), cdiv(p.N, 64));
-    hipLaunchKernelGGL((conv_gemm_nn<64, 64, 32>), g, dim3(256), 0, stream, p);
+    launch_nn(p, stream);
     TACO_RETURN_LAST();
 }
 
