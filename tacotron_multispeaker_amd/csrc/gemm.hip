@@ -505,6 +505,183 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
 }
 
 // =====================================================================================================
+// NT v2 (input gradient), same construction as NN v2: both operands k-contiguous (dY rows, W[j][c][:] rows), both staged
+// unpadded + XOR-swizzled via buffer_load ... lds, VALU-free K loop, ring of STAGES static LDS stages.  blockIdx.z owns a
+// contiguous share of the flattened (kw, tap, k chunk) steps (split-K, atomically accumulated) like v1.
+// =====================================================================================================
+template <int BM, int BN, int BK>
+struct MmaSw2 {
+    static constexpr int MI = BM / 64, NI = BN / 64, KK = BK / 8;
+    int aaddr[MI][KK], baddr[NI][KK];
+    __device__ __forceinline__ void init(int wm, int wn, int lane) {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * (BM / 2) + mi * 32 + i;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) aaddr[mi][kk] = row * BK + (((kk * 2 + h) ^ ((row / (64 / BK)) & (BK / 4 - 1))) << 2);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = wn * (BN / 2) + ni * 32 + i;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) baddr[ni][kk] = col * BK + (((kk * 2 + h) ^ ((col / (64 / BK)) & (BK / 4 - 1))) << 2);
+        }
+    }
+    __device__ __forceinline__ void run(const float* __restrict__ As, const float* __restrict__ Bs, f32x16 (&acc)[MI][NI]) const {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            float a[MI][4], b[NI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const float4 v = *reinterpret_cast<const float4*>(&As[aaddr[mi][kk]]);
+                a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float4 v = *reinterpret_cast<const float4*>(&Bs[baddr[ni][kk]]);
+                b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][q], b[ni][q], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+template <int BM, int BN, int BK, int STAGES, bool KTAIL>
+__global__ __launch_bounds__(256) void conv_gemm_nt2(ConvGemm p) {
+    constexpr int ASZ = BM * BK, BSZ = BN * BK, SSZ = ASZ + BSZ;
+    constexpr int CPR = BK / 4;             // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;           // rows per wave-instruction (1 KiB)
+    constexpr int NVA = BM / (RPI * 4), NVB = BN / (RPI * 4), LPS = NVA + NVB;
+    static_assert(NVA >= 1 && NVB >= 1 && (STAGES == 2 || STAGES == 3), "tile config");
+    __shared__ __attribute__((aligned(16))) float smem[STAGES][SSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int ksteps = (p.K + BK - 1) / BK;
+    const int ldb = p.bank ? p.cpb : p.ldb;
+
+    int total = 0;
+    for (int kw = p.kw_lo; kw <= p.kw_hi; ++kw) total += kw * ksteps;
+    const int per = (total + p.splitk - 1) / p.splitk;
+    const int s_begin = blockIdx.z * per, s_end = min(total, s_begin + per);
+    if (s_begin >= s_end) return;
+    const int nsteps = s_end - s_begin;
+    int l_kw = p.kw_lo, l_j = 0, l_kc = 0;                               // next tile to issue
+    {
+        int skip = s_begin;
+        while (skip >= l_kw * ksteps) { skip -= l_kw * ksteps; ++l_kw; }
+        l_j = skip / ksteps; l_kc = skip - l_j * ksteps;
+    }
+
+    int tpos[NVA], acol[NVA];
+    unsigned arow[NVA];
+    bool arok[NVA];
+#pragma unroll
+    for (int v = 0; v < NVA; ++v) {
+        const int r = (v * 4 + wave) * RPI + lane / CPR;
+        tpos[v] = (m0 + r) % p.T;
+        arow[v] = (unsigned)rowmap(p, m0 + r);
+        arok[v] = m0 + r < p.M;
+        acol[v] = ((lane % CPR) ^ ((r / (64 / BK)) & (CPR - 1))) * 4;
+    }
+    unsigned voa[NVA], voa_last[NVA], vob[NVB], vob_last[NVB];
+    const int klast = (ksteps - 1) * BK;
+#pragma unroll
+    for (int v = 0; v < NVB; ++v) {
+        const int r = (v * 4 + wave) * RPI + lane / CPR;
+        const int bcol = ((lane % CPR) ^ ((r / (64 / BK)) & (CPR - 1))) * 4;
+        vob[v] = n0 + r < p.N ? (unsigned)((n0 + r) * ldb + bcol) * 4u : TACO_OOB;
+        vob_last[v] = klast + bcol < p.K ? vob[v] : TACO_OOB;
+    }
+    int sob_tap = 0, aoff = 0;
+    bool need_tap = true;
+    auto tap_offsets = [&]() {
+        const int shift = -(l_j - (l_kw - 1) / 2);
+        aoff = p.bank ? (l_kw - 1) * p.cpb : 0;
+        sob_tap = __builtin_amdgcn_readfirstlane(((p.bank ? p.N * p.cpb * ((l_kw - 1) * l_kw / 2) : 0) + l_j * p.N * ldb) * 4);
+#pragma unroll
+        for (int v = 0; v < NVA; ++v) {
+            const bool ok = arok[v] && (unsigned)(tpos[v] + shift) < (unsigned)p.T;
+            voa[v] = ok ? ((arow[v] + shift) * (unsigned)p.lda + acol[v]) * 4u : TACO_OOB;
+            voa_last[v] = klast + acol[v] < p.K ? voa[v] : TACO_OOB;
+        }
+    };
+    int issued = 0;
+    auto issue = [&](float* stage) {
+        if (need_tap) { tap_offsets(); need_tap = false; }
+        const bool last = KTAIL && l_kc == ksteps - 1;
+        const int soa = (aoff + l_kc * BK) * 4, sob = sob_tap + l_kc * BK * 4;
+#pragma unroll
+        for (int v = 0; v < NVA; ++v)
+            buf_load_lds16(p.A, stage + (v * 4 + wave) * RPI * BK, last ? voa_last[v] : voa[v], soa);
+#pragma unroll
+        for (int v = 0; v < NVB; ++v)
+            buf_load_lds16(p.B, stage + ASZ + (v * 4 + wave) * RPI * BK, last ? vob_last[v] : vob[v], sob);
+        ++issued;
+        if (++l_kc == ksteps) { l_kc = 0; need_tap = true; if (++l_j == l_kw) { l_j = 0; ++l_kw; } }
+    };
+
+    f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < BN / 64; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    MmaSw2<BM, BN, BK> mm;
+    mm.init(wm, wn, lane);
+
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nsteps) issue(smem[t]);
+    if (STAGES == 3 && nsteps >= 2) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+    __syncthreads();
+    const int ngroups = nsteps / STAGES;
+    for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+        for (int u = 0; u < STAGES; ++u) {
+            const bool more = issued < nsteps;
+            if (more) issue(smem[(u + STAGES - 1) % STAGES]);
+            mm.run(smem[u], smem[u] + ASZ, acc);
+            if (STAGES == 3 && more) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __syncthreads();
+        }
+    }
+    const int rem = nsteps - ngroups * STAGES;
+    if (rem >= 1) {
+        mm.run(smem[0], smem[0] + ASZ, acc);
+        if (STAGES == 3 && rem == 2) {
+            wait_vmcnt<0>();
+            __syncthreads();
+            mm.run(smem[1], smem[1] + ASZ, acc);
+        }
+    }
+    if (p.splitk == 1) { epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane); return; }
+    const int i = lane & 31, h = lane >> 5;         // split-K: partial sums are atomically added into (zeroed) C
+#pragma unroll
+    for (int ni = 0; ni < BN / 64; ++ni) {
+        const int col = n0 + wn * (BN / 2) + ni * 32 + i;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.M) atomicAdd(p.C + rowmap(p, row) * p.ldc + col, acc[mi][ni][r]);
+            }
+    }
+}
+
+// =====================================================================================================
 // TN: dW_kw[j][c][n] += sum_m X[m + j - pl, c] * dY[m, aoff(kw) + n]                     (weight gradient)
 //     p.M = reduction rows, p.K = Cin (output rows), p.N = Cout per conv (output cols);
 //     grid.z = segment(kw,j) * splitk + split; partial sums are atomically added into pre-zeroed C.
@@ -568,6 +745,170 @@ __global__ __launch_bounds__(256) void conv_gemm_tn(ConvGemm p) {
             TB::store(smem[cur ^ 1] + BK * BM, tid, rb);
         }
         __syncthreads();
+    }
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < BN / 64; ++ni) {
+        const int col = n0 + wn * (BN / 2) + ni * 32 + i;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.K) atomicAdd(Cw + (long)row * ldc + col, acc[mi][ni][r]);
+            }
+    }
+}
+
+// =====================================================================================================
+// TN v2 (weight gradient): reduction over rows; X tile [BK rows][BM channels] and dY tile [BK rows][BN channels], both
+// k-strided in LDS, loaded with buffer_load ... lds.  Row masks (sequence edges for a shifted tap, ragged M) only matter
+// for a minority of row tiles: a scalar test picks precomputed lane offsets for interior tiles and computes masked
+// offsets (VALU) only for edge tiles, so the steady-state K loop issues no VALU work.  The shift is folded into the
+// buffer base so that lane offsets stay non-negative.
+// =====================================================================================================
+template <int BM, int BN, int BK>
+struct MmaKs {
+    static constexpr int MI = BM / 64, NI = BN / 64, KK = BK / 8;
+    int aaddr[MI], baddr[NI];
+    __device__ __forceinline__ void init(int wm, int wn, int lane) {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) aaddr[mi] = 4 * h * BM + wm * (BM / 2) + mi * 32 + i;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) baddr[ni] = 4 * h * BN + wn * (BN / 2) + ni * 32 + i;
+    }
+    __device__ __forceinline__ void run(const float* __restrict__ As, const float* __restrict__ Bs, f32x16 (&acc)[MI][NI]) const {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            float a[MI][4], b[NI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[mi][q] = As[aaddr[mi] + (kk * 8 + q) * BM];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[ni][q] = Bs[baddr[ni] + (kk * 8 + q) * BN];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][q], b[ni][q], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+template <int BM, int BN, int BK, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_tn2(ConvGemm p) {
+    constexpr int ASZ = BK * BM, BSZ = BK * BN, SSZ = ASZ + BSZ;
+    constexpr int RA = 256 / BM, RBn = 256 / BN;            // rows per wave-instruction (1 KiB)
+    constexpr int NVA = BK / (RA * 4), NVB = BK / (RBn * 4), LPS = NVA + NVB;
+    constexpr int LPRA = BM / 4, LPRB = BN / 4;             // lanes per row
+    static_assert(NVA >= 1 && NVB >= 1 && (STAGES == 2 || STAGES == 3), "tile config");
+    __shared__ __attribute__((aligned(16))) float smem[STAGES][SSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int seg = blockIdx.z / p.splitk;
+    const int split = blockIdx.z - seg * p.splitk;
+    int kw = p.kw_lo, j = seg;
+    if (p.bank) { kw = 1; while (seg >= kw) { seg -= kw; ++kw; } j = seg; }
+    const int shift = j - (kw - 1) / 2 + p.shift0;
+    const int aoff = p.bank ? (kw - 1) * p.cpb : 0;
+    const int ldc = p.bank ? p.cpb : p.ldc;
+    float* Cw = p.C + (p.bank ? (long)p.K * p.cpb * ((kw - 1) * kw / 2) : 0) + (long)j * p.K * ldc;
+
+    const int ktiles = (p.M + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt0 = split * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+    const int nsteps = kt1 - kt0;
+    const float* Ab = p.A + (long)shift * p.lda;             // row m of this view is X[m + shift]
+    const float* Bbase = p.B + aoff;
+
+    int mla[NVA], mlb[NVB];
+    unsigned voa_in[NVA], vob_in[NVB];
+#pragma unroll
+    for (int v = 0; v < NVA; ++v) {
+        mla[v] = (v * 4 + wave) * RA + lane / LPRA;
+        const int c = c0 + (lane % LPRA) * 4;
+        voa_in[v] = c < p.K ? (unsigned)(mla[v] * p.lda + c) * 4u : TACO_OOB;
+    }
+#pragma unroll
+    for (int v = 0; v < NVB; ++v) {
+        mlb[v] = (v * 4 + wave) * RBn + lane / LPRB;
+        const int n = n0 + (lane % LPRB) * 4;
+        vob_in[v] = n < p.N ? (unsigned)(mlb[v] * p.ldb + n) * 4u : TACO_OOB;
+    }
+    int i_kt = kt0, issued = 0;
+    int t0 = (kt0 * BK) % p.T;                               // position of the tile's first row inside its sequence
+    const int astep = BK * p.lda * 4, bstep = BK * p.ldb * 4;
+    int soa = __builtin_amdgcn_readfirstlane(kt0 * astep), sob = __builtin_amdgcn_readfirstlane(kt0 * bstep);
+    auto issue = [&](float* stage) {
+        const int mbase = i_kt * BK;
+        const bool full = mbase + BK <= p.M;
+        const bool interior = full && (shift == 0 || (t0 + shift >= 0 && t0 + BK - 1 + shift < p.T && t0 + BK - 1 < p.T));
+        if (interior) {
+#pragma unroll
+            for (int v = 0; v < NVA; ++v) buf_load_lds16(Ab, stage + (v * 4 + wave) * RA * BM, voa_in[v], soa);
+        } else {
+#pragma unroll
+            for (int v = 0; v < NVA; ++v) {
+                const int m = mbase + mla[v];
+                const bool ok = m < p.M && (unsigned)(m % p.T + shift) < (unsigned)p.T;
+                buf_load_lds16(Ab, stage + (v * 4 + wave) * RA * BM, ok ? voa_in[v] : TACO_OOB, soa);
+            }
+        }
+        if (full) {
+#pragma unroll
+            for (int v = 0; v < NVB; ++v) buf_load_lds16(Bbase, stage + ASZ + (v * 4 + wave) * RBn * BN, vob_in[v], sob);
+        } else {
+#pragma unroll
+            for (int v = 0; v < NVB; ++v)
+                buf_load_lds16(Bbase, stage + ASZ + (v * 4 + wave) * RBn * BN, mbase + mlb[v] < p.M ? vob_in[v] : TACO_OOB, sob);
+        }
+        ++i_kt; ++issued; soa += astep; sob += bstep;
+        t0 += BK; if (t0 >= p.T) t0 %= p.T;
+    };
+
+    f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < BN / 64; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    MmaKs<BM, BN, BK> mm;
+    mm.init(wm, wn, lane);
+
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nsteps) issue(smem[t]);
+    if (STAGES == 3 && nsteps >= 2) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+    __syncthreads();
+    const int ngroups = nsteps / STAGES;
+    for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+        for (int u = 0; u < STAGES; ++u) {
+            const bool more = issued < nsteps;
+            if (more) issue(smem[(u + STAGES - 1) % STAGES]);
+            mm.run(smem[u], smem[u] + ASZ, acc);
+            if (STAGES == 3 && more) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __syncthreads();
+        }
+    }
+    const int rem = nsteps - ngroups * STAGES;
+    if (rem >= 1) {
+        mm.run(smem[0], smem[0] + ASZ, acc);
+        if (STAGES == 3 && rem == 2) {
+            wait_vmcnt<0>();
+            __syncthreads();
+            mm.run(smem[1], smem[1] + ASZ, acc);
+        }
     }
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -678,6 +1019,58 @@ extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* b
     TACO_RETURN_LAST();
 }
 
+// ---- NT dispatch (input gradient) ------------------------------------------------------------------------------------
+#define NT2_LAUNCH(BM_, BN_, BK_, ST_) do { dim3 g2(cdiv(p.M, BM_), cdiv(p.N, BN_), p.splitk); \
+        if (p.K % BK_) hipLaunchKernelGGL((conv_gemm_nt2<BM_, BN_, BK_, ST_, true>), g2, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((conv_gemm_nt2<BM_, BN_, BK_, ST_, false>), g2, dim3(256), 0, stream, p); } while (0)
+
+static bool fits31_nt(const ConvGemm& p) {
+    const long abytes = (max_phys_row(p) + 1 + p.kw_hi) * (long)p.lda * 4;
+    long wrows = 0;                                                      // W rows of length ldb: [taps][Cin]
+    for (int k = p.kw_lo; k <= p.kw_hi; ++k) wrows += (long)k * p.N;
+    const long bbytes = (wrows + 64) * (long)(p.bank ? p.cpb : p.ldb) * 4;
+    return abytes < (1L << 31) && bbytes < (1L << 31);
+}
+
+// returns the split count chosen (the caller zero-fills C when > 1 and not accumulating)
+static int plan_nt(ConvGemm& p) {
+    const long tiles = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
+    int nsteps = 0;
+    for (int k = p.kw_lo; k <= p.kw_hi; ++k) nsteps += k * cdiv(p.K, 32);
+    int splitk = 1;
+    if (tiles < 256 && nsteps >= 64) {      // few output tiles but a long reduction (conv bank dX): split the taps
+        splitk = (int)((768 + tiles - 1) / tiles);
+        if (splitk > nsteps / 16) splitk = nsteps / 16;
+        if (splitk < 1) splitk = 1;
+    }
+    p.splitk = splitk;
+    return splitk;
+}
+
+static void launch_nt(const ConvGemm& p, hipStream_t stream) {
+    static const int force_v1 = env_int("TACO_NT_V1", 0), force_cfg = env_int("TACO_NT2_TILE", -1);
+    if (force_v1 || !fits31_nt(p)) {
+        dim3 g(cdiv(p.M, 64), cdiv(p.N, 64), p.splitk);
+        hipLaunchKernelGGL((conv_gemm_nt<64, 64, 32>), g, dim3(256), 0, stream, p);
+        return;
+    }
+    int cfg = force_cfg;
+    if (cfg < 0) {
+        const int k32 = cdiv(p.K, 32) * 32;
+        int nsteps = 0;
+        for (int k = p.kw_lo; k <= p.kw_hi; ++k) nsteps += k * (k32 / 32);
+        const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+        if (tiles128 >= 2048 && p.splitk == 1) cfg = 3;
+        else if ((k32 - p.K) * 8 > p.K) cfg = 2;
+        else if (nsteps / p.splitk <= 16) cfg = 1;
+        else cfg = 0;
+    }
+    if (cfg == 1) NT2_LAUNCH(64, 64, 32, 2);
+    else if (cfg == 2) NT2_LAUNCH(64, 64, 16, 3);
+    else if (cfg == 3) NT2_LAUNCH(128, 128, 16, 3);
+    else NT2_LAUNCH(64, 64, 32, 3);
+}
+
 extern "C" int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* dX, int M, int T, int Cin, int Cout,
                                        int kw, int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream) {
     ConvGemm p{};
@@ -687,27 +1080,10 @@ extern "C" int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* d
     else { p.bank = 0; p.K = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
     if (int e = check_common(p)) return e;
     if (M % T != 0 || kw < 1) return TACO_EINVAL;
-    const long tiles128 = (long)cdiv(M, 128) * cdiv(p.N, 128);
-    if (forced_tile() == 128) {
-        dim3 g(cdiv(M, 128), cdiv(p.N, 128));
-        hipLaunchKernelGGL((conv_gemm_nt<128, 128, 16>), g, dim3(256), 0, stream, p);
-    } else {
-        // few output tiles but a long reduction (conv bank dX): split the taps over blockIdx.z, atomically accumulate
-        const long tiles = (long)cdiv(M, 64) * cdiv(p.N, 64);
-        int nsteps = 0;
-        for (int k = p.kw_lo; k <= p.kw_hi; ++k) nsteps += k * cdiv(p.K, 32);
-        int splitk = 1;
-        if (tiles < 256 && nsteps >= 64) {
-            splitk = (int)((768 + tiles - 1) / tiles);
-            if (splitk > nsteps / 16) splitk = nsteps / 16;
-            if (splitk < 1) splitk = 1;
-        }
-        p.splitk = splitk;
-        if (splitk > 1 && !accumulate)
-            if (hipMemset2DAsync(dX, (size_t)lddx * sizeof(float), 0, (size_t)Cin * sizeof(float), M, stream) != hipSuccess) return TACO_EINVAL;
-        dim3 g(cdiv(M, 64), cdiv(p.N, 64), splitk);
-        hipLaunchKernelGGL((conv_gemm_nt<64, 64, 32>), g, dim3(256), 0, stream, p);
-    }
+    const int splitk = plan_nt(p);
+    if (splitk > 1 && !accumulate)
+        if (hipMemset2DAsync(dX, (size_t)lddx * sizeof(float), 0, (size_t)Cin * sizeof(float), M, stream) != hipSuccess) return TACO_EINVAL;
+    launch_nt(p, stream);
     TACO_RETURN_LAST();
 }
 
@@ -723,21 +1099,30 @@ static int conv_gemm_bwd_weight_impl(const float* X, const float* dY, float* dW,
     else { p.bank = 0; p.N = Cout; p.ldc = ldw; p.kw_lo = p.kw_hi = kw; nseg = kw; }
     if (int e = check_common(p)) return e;
     if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
-    // 128x128 tiles only when there are enough of them; few-tile shapes (highway, GRU projections) run 1.5-1.9x faster
-    // on 64x64 tiles with a deeper split over the rows (scripts/dev_gemm.py)
-    const bool big = forced_tile() == 64 ? false
-                                         : (p.K >= 128 && p.N >= 128 && (long)cdiv(p.K, 128) * cdiv(p.N, 128) * nseg >= 16);
+    // Measured with scripts/gemm_bench.hip (MODE=bwd_weight) on MI355X: with the v2 kernel 64x64x32 tiles match or beat
+    // 128x128x16 on every model shape (fewer atomics per output element at equal workgroup count); big tiles only pay
+    // for >= 512 of them.  The reduction is split until ~2048 workgroups exist, keeping >= 12 row tiles per workgroup.
+    static const int tn_big = env_int("TACO_TN_BIG", -1), tn_wgs = env_int("TACO_TN_WGS", 2048);
+    const bool big = tn_big >= 0 ? tn_big != 0
+                                 : (p.K >= 128 && p.N >= 128 && (long)cdiv(p.K, 128) * cdiv(p.N, 128) * nseg >= 512);
     const int bm = big ? 128 : 64, bk = big ? 16 : 32;
     const long tiles = (long)cdiv(p.K, bm) * cdiv(p.N, bm) * nseg;
     const int ktiles = cdiv(M, bk);
-    int splitk = (int)((1024 + tiles - 1) / tiles);
-    const int max_split = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    int splitk = (int)((tn_wgs + tiles - 1) / tiles);
+    const int max_split = ktiles / 12 > 0 ? ktiles / 12 : 1;
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
     p.splitk = splitk;
     dim3 g(cdiv(p.K, bm), cdiv(p.N, bm), nseg * splitk);
-    if (big) hipLaunchKernelGGL((conv_gemm_tn<128, 128, 16>), g, dim3(256), 0, stream, p);
-    else     hipLaunchKernelGGL((conv_gemm_tn<64, 64, 32>), g, dim3(256), 0, stream, p);
+    static const int force_v1 = env_int("TACO_TN_V1", 0);
+    // v2 needs 31-bit byte offsets into X (plus the shifted rows) and dY
+    const bool v2 = !force_v1 && ((long)M + 64) * ldx * 4 < (1L << 31) && ((long)M + 64) * lddy * 4 < (1L << 31);
+    if (!v2) {
+        if (big) hipLaunchKernelGGL((conv_gemm_tn<128, 128, 16>), g, dim3(256), 0, stream, p);
+        else     hipLaunchKernelGGL((conv_gemm_tn<64, 64, 32>), g, dim3(256), 0, stream, p);
+    } else if (big) hipLaunchKernelGGL((conv_gemm_tn2<128, 128, 16, 3>), g, dim3(256), 0, stream, p);
+    else if (cdiv(ktiles, splitk) <= 8) hipLaunchKernelGGL((conv_gemm_tn2<64, 64, 32, 2>), g, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_tn2<64, 64, 32, 3>), g, dim3(256), 0, stream, p);
     TACO_RETURN_LAST();
 }
 
@@ -778,7 +1163,6 @@ extern "C" int taco_dense_rows_bwd_data(const float* dY, const float* W, float* 
     p.accumulate = accumulate; p.splitk = 1; p.kw_lo = p.kw_hi = 1; p.rb_len = ch; p.rb_stride = S; p.rb_off = s0;
     if (ch <= 0 || s0 < 0 || s1 > S) return TACO_EINVAL;
     if (int e = check_common(p)) return e;
-    dim3 g(cdiv(M, 64), cdiv(p.N, 64), 1);
-    hipLaunchKernelGGL((conv_gemm_nt<64, 64, 32>), g, dim3(256), 0, stream, p);
+    launch_nt(p, stream);
     TACO_RETURN_LAST();
 }
