@@ -59,6 +59,10 @@ int taco_embed_scatter_bwd(const int* ids, const int* identities, const float* d
 
 /* ---- batch norm (tf.layers.batch_normalization, models/modules.py:101), maxpool (modules.py:45-49), residual -- */
 int taco_col_sum(const float* x, int ldx, float* out, int M, int C, hipStream_t stream);   /* out[c] += sum_m x[m,c] */
+/* dstat_zeroed: TACO_BN_DSTAT(C) doubles of zeroed scratch (replicated per-column sums; same-address atomics from
+ * hundreds of workgroups serialise in L2, so the reductions land in TACO_BN_REPL replicas that the consumers add up) */
+#define TACO_BN_REPL 8
+#define TACO_BN_DSTAT(C) (TACO_BN_REPL * 3 * (C))
 int taco_bn_stats_fwd(const float* x, int ldx, const float* gamma, const float* beta, double* dstat_zeroed, float* mean,
                       float* var, float* rstd, float* scale, float* shift, int M, int C, float eps, hipStream_t stream);
 int taco_bn_infer_params(const float* moving_mean, const float* moving_var, const float* gamma, const float* beta,

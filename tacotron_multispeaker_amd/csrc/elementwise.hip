@@ -156,10 +156,13 @@ __global__ __launch_bounds__(256) void col_reduce_k(ColRed p) {
             atomicAdd(p.out0 + c + 0, a.x); atomicAdd(p.out0 + c + 1, a.y);
             atomicAdd(p.out0 + c + 2, a.z); atomicAdd(p.out0 + c + 3, a.w);
         } else {
-            atomicAdd(p.dstat + c + 0, (double)a.x); atomicAdd(p.dstat + c + 1, (double)a.y);
-            atomicAdd(p.dstat + c + 2, (double)a.z); atomicAdd(p.dstat + c + 3, (double)a.w);
-            atomicAdd(p.dstat + p.C + c + 0, (double)b.x); atomicAdd(p.dstat + p.C + c + 1, (double)b.y);
-            atomicAdd(p.dstat + p.C + c + 2, (double)b.z); atomicAdd(p.dstat + p.C + c + 3, (double)b.w);
+            // TACO_BN_REPL replicas of the per-column sums: same-address double atomics from hundreds of workgroups
+            // serialise in L2 (34 us for a 21 MB tensor); the consumers add the replicas up
+            double* ds = p.dstat + (long)(blockIdx.y % TACO_BN_REPL) * 3 * p.C;
+            atomicAdd(ds + c + 0, (double)a.x); atomicAdd(ds + c + 1, (double)a.y);
+            atomicAdd(ds + c + 2, (double)a.z); atomicAdd(ds + c + 3, (double)a.w);
+            atomicAdd(ds + p.C + c + 0, (double)b.x); atomicAdd(ds + p.C + c + 1, (double)b.y);
+            atomicAdd(ds + p.C + c + 2, (double)b.z); atomicAdd(ds + p.C + c + 3, (double)b.w);
         }
     }
 }
@@ -177,14 +180,16 @@ static void col_reduce_grid(int M, int C, dim3& g, int& rpb) {
 // =====================================================================================================
 // BatchNorm (tf.layers.batch_normalization, training mode; modules.py:101)
 // =====================================================================================================
-// stats double[2C] (sum, sumsq over M rows) -> mean, var(biased), rstd, scale=gamma*rstd, shift=beta-mean*scale
+// stats double[TACO_BN_REPL][3C] (replicated sum, sumsq over M rows) -> mean, var(biased), rstd, scale=gamma*rstd, shift=beta-mean*scale
 __global__ void bn_finalize_k(const double* __restrict__ dstat, const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ mean, float* __restrict__ var, float* __restrict__ rstd,
                               float* __restrict__ scale, float* __restrict__ shift, int M, int C, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mu = dstat[c] / M;
-    double v = dstat[C + c] / M - mu * mu;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < TACO_BN_REPL; ++r) { s0 += dstat[(long)r * 3 * C + c]; s1 += dstat[(long)r * 3 * C + C + c]; }
+    const double mu = s0 / M;
+    double v = s1 / M - mu * mu;
     if (v < 0.0) v = 0.0;
     const float r = (float)(1.0 / sqrt(v + (double)eps));
     mean[c] = (float)mu; var[c] = (float)v; rstd[c] = r;
@@ -245,8 +250,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwd p) {
         const float4 sh = *reinterpret_cast<const float4*>(q.shift + c);
         const float4 mu = *reinterpret_cast<const float4*>(q.mean + c);
         const float4 rs = *reinterpret_cast<const float4*>(q.rstd + c);
-        const float sdb[4] = {(float)q.dstat[c], (float)q.dstat[c + 1], (float)q.dstat[c + 2], (float)q.dstat[c + 3]};
-        const float sdx[4] = {(float)q.dstat[q.C + c], (float)q.dstat[q.C + c + 1], (float)q.dstat[q.C + c + 2], (float)q.dstat[q.C + c + 3]};
+        float sdb[4], sdx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r < TACO_BN_REPL; ++r) { a += q.dstat[(long)r * 3 * q.C + c + k]; b += q.dstat[(long)r * 3 * q.C + q.C + c + k]; }
+            sdb[k] = (float)a; sdx[k] = (float)b;
+        }
         const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w}, scs[4] = {sc.x, sc.y, sc.z, sc.w};
         for (long m = r0 + ty; m < r1; m += 4) {
             const float4 xv = *reinterpret_cast<const float4*>(q.x + m * q.ldx + c);
@@ -272,13 +282,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwd p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float t = red[k][0][tx] + red[k][1][tx] + red[k][2][tx] + red[k][3][tx];
-            if (p.dbias) atomicAdd(p.dbias + c + k, t);              // conv bias gradient = sum_m dx[m, c]
-            if (blockIdx.y == 0) {
-                p.dgamma[c + k] += (float)q.dstat[q.C + c + k];
-                p.dbeta[c + k] += (float)q.dstat[c + k];
-            }
+            if (p.dbias)                                             // conv bias gradient = sum_m dx[m, c] (replicated, see above)
+                atomicAdd(q.dstat + (long)(blockIdx.y % TACO_BN_REPL) * 3 * q.C + 2 * q.C + c + k, (double)t);
         }
     }
+}
+
+// dgamma += sum dY*xhat, dbeta += sum dY, dbias += sum dx (replica sums of the two kernels above)
+__global__ void bn_bwd_finish_k(const double* __restrict__ dstat, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                float* __restrict__ dbias, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < TACO_BN_REPL; ++r) {
+        s0 += dstat[(long)r * 3 * C + c]; s1 += dstat[(long)r * 3 * C + C + c]; s2 += dstat[(long)r * 3 * C + 2 * C + c];
+    }
+    dgamma[c] += (float)s1;
+    dbeta[c] += (float)s0;
+    if (dbias) dbias[c] += (float)s2;
 }
 
 // =====================================================================================================
@@ -463,6 +484,7 @@ extern "C" int taco_bn_bwd(const float* x, int ldx, const float* dy, int lddy, c
     hipLaunchKernelGGL(col_reduce_k<2>, g, dim3(256), 0, stream, p);
     b.gamma = gamma; b.dgamma = dgamma; b.dbeta = dbeta; b.dbias = dbias; b.dx = dx; b.lddx = lddx; b.relu = relu;
     hipLaunchKernelGGL(bn_bwd_apply_k, g, dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(bn_bwd_finish_k, dim3(cdiv(C, 256)), dim3(256), 0, stream, dstat_zeroed, dgamma, dbeta, dbias, C);
     TACO_RETURN_LAST();
 }
 

@@ -50,17 +50,19 @@ class Engine:
         self.bn = torch.zeros(max(L.bn_total, 4), **f)              # moving mean / variance
         self.bnbatch = torch.zeros(max(L.bn_total, 4), **f)         # batch mean / variance of the last step
         self.global_step = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.dscratch = torch.zeros(1 << 16, dtype=torch.float64, device=self.dev)   # zeroed once per step
+        self.dscratch = torch.zeros(1 << 18, dtype=torch.float64, device=self.dev)   # zeroed once per step
         self.info = torch.zeros(4, **f)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._bufs = {}
         self._dpos = 0
-        self.side_stream = torch.cuda.Stream(device=self.dev)
+        self.side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, int(os.environ.get('TACO_SIDE_STREAMS', '1'))))]
+        self._side_rr = 0
         self._side_active = False
         self._deferred = []
         self.stream_b = torch.cuda.Stream(device=self.dev)      # decoder pipeline stages (GRU1 / GRU2 or attention)
         self.stream_c = torch.cuda.Stream(device=self.dev)
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
+        self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
         self.overlap_wgrad = True
         self.world = 1
         self.load_named(named_params if named_params is not None else init_named(L, seed))
@@ -138,10 +140,14 @@ class Engine:
             return
         ev = torch.cuda.Event()
         ev.record()
-        self.side_stream.wait_event(ev)
-        with torch.cuda.stream(self.side_stream):
-            for fn in self._deferred:
+        for ss in self.side_streams:
+            ss.wait_event(ev)
+        # independent weight-gradient launches (distinct outputs, atomic accumulation) are dealt round-robin over the side
+        # streams, so that the many short ones at the end of backward do not serialise behind each other
+        for fn in self._deferred:
+            with torch.cuda.stream(self.side_streams[self._side_rr % len(self.side_streams)]):
                 fn()
+            self._side_rr += 1
         self._deferred = []
 
     def gemm_dw(self, X, dY, dW, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, lddy=None, ldw=None):
@@ -168,7 +174,7 @@ class Engine:
     def bn_fwd(self, scope, x, M, C, training):
         sc, sh = self.buf(scope + '/bn_scale', C), self.buf(scope + '/bn_shift', C)
         if training:
-            lib.taco_bn_stats_fwd(x, x.stride(-2), self.P(scope + '/gamma'), self.P(scope + '/beta'), self.dslot(2 * C),
+            lib.taco_bn_stats_fwd(x, x.stride(-2), self.P(scope + '/gamma'), self.P(scope + '/beta'), self.dslot(24 * C),
                                   self.L.bnview(self.bnbatch, scope + '/moving_mean'),
                                   self.L.bnview(self.bnbatch, scope + '/moving_variance'),
                                   self.buf(scope + '/bn_rstd', C), sc, sh, M, C, BN_EPS, self.st)
@@ -181,7 +187,7 @@ class Engine:
     def bn_bwd(self, scope, x, dy, dx, M, C, T, pool, relu):
         lib.taco_bn_bwd(x, x.stride(-2), dy, dy.stride(-2), self.L.bnview(self.bnbatch, scope + '/moving_mean'),
                         self.buf(scope + '/bn_rstd', C), self.buf(scope + '/bn_scale', C), self.buf(scope + '/bn_shift', C),
-                        self.P(scope + '/gamma'), self.dslot(2 * C), self.G(scope + '/gamma'), self.G(scope + '/beta'),
+                        self.P(scope + '/gamma'), self.dslot(24 * C), self.G(scope + '/gamma'), self.G(scope + '/beta'),
                         self.G(scope + '/bias'), dx, dx.stride(-2), M, C, T, pool, relu, self.st)
 
     # ---- CBHG (models/modules.py:35-74) ----------------------------------------------------------------------------
@@ -346,9 +352,9 @@ class Engine:
         self.encoder_outputs = ENC.view(N, Ti, 256)
         return MEL, LIN, self.alignments
 
-    def _chunks(self, N, S, Ti):
+    def _chunks(self, N, S, Ti, k=None):
         """Step ranges for the chunk-pipelined decoder (needs the cluster path); [(0, S)] = no pipelining."""
-        k = self.pipe_chunks
+        k = k or self.pipe_chunks
         if k <= 1 or S < 2 * k or not lib.load().taco_attn_cluster_supported(N, Ti):
             return [(0, S)]
         step = (S + k - 1) // k
@@ -483,7 +489,7 @@ class Engine:
         self.dense_bwd(D2, dOUT, 'output_projection', Ms, 256, nm * r, dx=dD)
         # Chunk-pipelined decoder backward (descending chunks): GRU2 BPTT on the current stream, GRU1 BPTT and the attention
         # BPTT on two more streams; the hoisted input-gradient projections of a chunk run between the stages.
-        chunks = self._chunks(N, S, Ti)[::-1]
+        chunks = self._chunks(N, S, Ti, self.pipe_chunks_bwd)[::-1]
         cur = torch.cuda.current_stream()
         sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
         dHC = b['dHC']
@@ -560,7 +566,8 @@ class Engine:
                                    N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
         if self._side_active:
             self.flush_side()
-            torch.cuda.current_stream().wait_stream(self.side_stream)      # join: all weight gradients are complete
+            for ss in self.side_streams:
+                torch.cuda.current_stream().wait_stream(ss)                # join: all weight gradients are complete
             self._side_active = False
 
     # ---- optimizer (models/tacotron.py:174-202) ---------------------------------------------------------------------------
