@@ -66,11 +66,11 @@ def time_dominant_kernel(eng, N, To, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * 3 * 1024 * 256
     # traffic: HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counter values;
-    # profiles/r01_pmc_post_proj1_conv.md) -- measured offline on the same kernel and shape, not in this run
-    return dict(kernel='conv_gemm_nn<64,64,32> (post_cbhg/proj_1 conv1d k=3 1024->256, M=%d)' % M,
+    # profiles/r01_pmc_gemm_v1_v2.md) -- measured offline on the same kernel and shape, not in this run
+    return dict(kernel='conv_gemm_nn2<64,64,32,3> (post_cbhg/proj_1 conv1d k=3 1024->256, M=%d)' % M,
                 bound='mfma', achieved=flops / (ms * 1e-3) / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                frac=flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=169.0e6 if M == 20480 else None,
-                traffic_unit='bytes/launch (148.5 MB FETCH_SIZE + 20.5 MB WRITE_SIZE; algorithmic 108 MB)',
+                frac=flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=181.2e6 if M == 20480 else None,
+                traffic_unit='bytes/launch (160.7 MB FETCH_SIZE + 20.5 MB WRITE_SIZE; algorithmic 108 MB)',
                 avg_launch_us=ms * 1e3, flops_per_launch=flops)
 
 
