@@ -71,6 +71,23 @@ __device__ __forceinline__ void dot2(const float* __restrict__ v0, const float* 
         a0 = fmaf(x0.w, w[k4 * 4 + 3], a0); a1 = fmaf(x1.w, w[k4 * 4 + 3], a1);
     }
 }
+// same, weights parked in LDS as per-thread float4 slots wl[(k4 * AT + tid) * 4 ..] (conflict-free b128 reads)
+template <int KPER>
+__device__ __forceinline__ void dot2_lds(const float* __restrict__ v0, const float* __restrict__ v1, int kbase,
+                                         const float* __restrict__ wl, int tid, float& a0, float& a1) {
+#pragma unroll
+    for (int k4 = 0; k4 < KPER / 4; ++k4) {
+        if (k4 && (k4 & 1) == 0) asm volatile("" ::: "memory");
+        const int k = kbase + k4 * 4;
+        const float4 x0 = *reinterpret_cast<const float4*>(v0 + PIDX(k));
+        const float4 x1 = *reinterpret_cast<const float4*>(v1 + PIDX(k));
+        const float4 wv = *reinterpret_cast<const float4*>(wl + (k4 * AT + tid) * 4);
+        a0 = fmaf(x0.x, wv.x, a0); a1 = fmaf(x1.x, wv.x, a1);
+        a0 = fmaf(x0.y, wv.y, a0); a1 = fmaf(x1.y, wv.y, a1);
+        a0 = fmaf(x0.z, wv.z, a0); a1 = fmaf(x1.z, wv.z, a1);
+        a0 = fmaf(x0.w, wv.w, a0); a1 = fmaf(x1.w, wv.w, a1);
+    }
+}
 template <int PARTS>
 __device__ __forceinline__ float lane_reduce(float v) { return group_sum<PARTS>(v); }
 
@@ -379,9 +396,9 @@ static size_t attn_cluster_smem(int Ti) {
 }
 
 // returns 1 when the cluster path can run this shape
-static size_t attn_cluster_bwd_smem(int Ti);
+static size_t attn_cluster_bwd_smem(int Ti, bool wlds);
 extern "C" int taco_attn_cluster_supported(int N, int Ti) {
-    return (CW * ((N + 1) / 2) <= 256 && attn_cluster_smem(Ti) <= 160 * 1024 && attn_cluster_bwd_smem(Ti) <= 160 * 1024 &&
+    return (CW * ((N + 1) / 2) <= 256 && attn_cluster_smem(Ti) <= 160 * 1024 && attn_cluster_bwd_smem(Ti, false) <= 160 * 1024 &&
             Ti >= 1 && Ti <= 512) ? 1 : 0;
 }
 
@@ -446,6 +463,11 @@ __device__ __forceinline__ void gather_off(const u64* region, float* lds0, float
     }
 }
 
+// WLDS: the prenet-gradient weight slices (Wx^T 24 + W2^T 8 floats per thread) live in LDS instead of registers.  With all
+// 112 weight floats in VGPRs the compiler spills ~58 loop-invariant dwords to scratch and reloads ~50 of them EVERY step
+// (each an exposed ~300-cycle scratch load on the recurrence chain: 16.2 vs 12.2 us/step); 64 KiB of LDS removes that.
+// The register variant remains for long inputs whose key/memory tiles need the LDS (Ti > ~150).
+template <bool WLDS>
 __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -482,17 +504,26 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     const int cB = tid >> 5, pB = tid & 31;     // 16 outputs x 32 parts
     const int jA = 32 * w + cA;                 // hidden / ctx / prenet-1 index of the A mapping
     const int jB = 16 * w + cB;                 // prenet-2 index
-    float wq[16], wc[16], wg[32], wx[24], w2[8], w1[16];
+    float* W_l = M_l + 2 * Ti * 32;                // WLDS: [6][AT][4] Wx^T slice, then [2][AT][4] W2^T slice
+    float wq[16], wc[16], wg[32], wx[WLDS ? 1 : 24], w2[WLDS ? 1 : 8], w1[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) wq[k] = p.wq[(long)jA * 256 + pA * 16 + k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) wc[k] = p.whc[(long)jA * 256 + pA * 16 + k];
 #pragma unroll
     for (int k = 0; k < 32; ++k) wg[k] = p.whg[(long)jA * 512 + pA * 32 + k];
+    if (WLDS) {
 #pragma unroll
-    for (int k = 0; k < 24; ++k) wx[k] = p.wx[(long)jB * 768 + pB * 24 + k];
+        for (int k = 0; k < 24; ++k) W_l[((k >> 2) * AT + tid) * 4 + (k & 3)] = p.wx[(long)jB * 768 + pB * 24 + k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w2[k] = p.w2[(long)jA * 128 + pA * 8 + k];
+        for (int k = 0; k < 8; ++k) W_l[((6 + (k >> 2)) * AT + tid) * 4 + (k & 3)] = p.w2[(long)jA * 128 + pA * 8 + k];
+        wx[0] = 0.f; w2[0] = 0.f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < (WLDS ? 1 : 24); ++k) wx[k] = p.wx[(long)jB * 768 + pB * 24 + k];
+#pragma unroll
+        for (int k = 0; k < (WLDS ? 1 : 8); ++k) w2[k] = p.w2[(long)jA * 128 + pA * 8 + k];
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) w1[k] = p.w1c[(long)jA * 256 + pA * 16 + k];
     const float vd = p.v[32 * w + (tid & 31)];            // dq mapping: d = tid & 31
@@ -687,7 +718,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
             if (pA == 0) { dhc0 = dhp[0] + a0; dhc1 = dhp[1] + a1; }
             float b0 = 0.f, b1 = 0.f;
-            dot2<24>(dxp_l, dxp_l + PLEN(768), pB * 24, wx, b0, b1);
+            if constexpr (WLDS) dot2_lds<24>(dxp_l, dxp_l + PLEN(768), pB * 24, W_l, tid, b0, b1);
+            else dot2<24>(dxp_l, dxp_l + PLEN(768), pB * 24, wx, b0, b1);
             b0 = lane_reduce<32>(b0); b1 = lane_reduce<32>(b1);
             if (pB == 0) {
                 b0 = p2v[0] > 0.f ? b0 : 0.f; b1 = p2v[1] > 0.f ? b1 : 0.f;
@@ -702,7 +734,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         // ================= X7: dp1pre = (dp2pre . W2^T) * (p1 > 0) =================
         {
             float a0 = 0.f, a1 = 0.f;
-            dot2<8>(dp2_l, dp2_l + PLEN(128), pA * 8, w2, a0, a1);
+            if constexpr (WLDS) dot2_lds<8>(dp2_l, dp2_l + PLEN(128), pA * 8, W_l + 6 * AT * 4, tid, a0, a1);
+            else dot2<8>(dp2_l, dp2_l + PLEN(128), pA * 8, w2, a0, a1);
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
             if (pA == 0) {
                 a0 = p1v[0] > 0.f ? a0 : 0.f; a1 = p1v[1] > 0.f ? a1 : 0.f;
@@ -763,9 +796,9 @@ __global__ __launch_bounds__(256) void attn_hoisted_bwd_k(const float* __restric
     dvpart[nt * 256 + d] = av;
 }
 
-static size_t attn_cluster_bwd_smem(int Ti) {
+static size_t attn_cluster_bwd_smem(int Ti, bool wlds = false) {
     size_t f = 2 * PLEN(256) + 2 * PLEN(768) + 2 * PLEN(128) + 2 * PLEN(256) + 64 + 64 + 3 * ((2 * Ti + 3) & ~3) + 512 +
-               (size_t)4 * Ti * 32;
+               (size_t)4 * Ti * 32 + (wlds ? 8 * AT * 4 : 0);
     return f * sizeof(float);
 }
 
@@ -776,13 +809,18 @@ extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_cluster_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_cluster_bwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_cluster_bwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return TACO_EINVAL;
         attr_set = true;
     }
-    if (attn_cluster_bwd_smem(p.Ti) > 160 * 1024) return TACO_EINVAL;
+    if (attn_cluster_bwd_smem(p.Ti, false) > 160 * 1024) return TACO_EINVAL;
     if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
-    hipLaunchKernelGGL(attn_cluster_bwd_k, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti), st, p);
+    static const bool no_wlds = getenv("TACO_ATTN_NO_WLDS") != nullptr;
+    if (!no_wlds && attn_cluster_bwd_smem(p.Ti, true) <= 160 * 1024)
+        hipLaunchKernelGGL(attn_cluster_bwd_k<true>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, true), st, p);
+    else
+        hipLaunchKernelGGL(attn_cluster_bwd_k<false>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, false), st, p);
     if (p.s0 == 0)       // all chunks done: reduce over the S steps
         hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3(p.Ti, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
                            dkeys, dmem, dvpart, p.S, p.Ti);

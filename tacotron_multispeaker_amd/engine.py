@@ -63,7 +63,7 @@ class Engine:
         self.stream_c = torch.cuda.Stream(device=self.dev)
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
-        self.overlap_wgrad = True
+        self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.world = 1
         self.load_named(named_params if named_params is not None else init_named(L, seed))
 
