@@ -36,6 +36,12 @@
 __device__ __forceinline__ void put_g(u64* p, unsigned epoch, float v) {
     __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// indexed put with an opaque index: the 64-bit lane address is formed at the store instead of being hoisted out of the
+// step loop as a live (and then spilled) VGPR pair
+__device__ __forceinline__ void put_gi(u64* base, unsigned idx, unsigned epoch, float v) {
+    asm volatile("" : "+v"(idx));
+    put_g(base + idx, epoch, v);
+}
 template <int NG>
 __device__ __forceinline__ void get_g(const u64* const (&ptr)[NG], unsigned epoch, float (&out)[NG], int* err) {
     u64 x[NG];
@@ -560,6 +566,14 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     __syncthreads();
 
     for (int s = p.s1 - 1; s >= p.s0; --s) {
+        // Re-derive the lane indices from an opaque copy of the thread id every step: otherwise every LDS / granule address
+        // built from them is hoisted out of the loop, and with 256 VGPRs full of weights the hoisted copies live in scratch
+        // (reloaded on the recurrence chain each step).
+        int tq = threadIdx.x;
+        asm volatile("" : "+v"(tq));
+        const int tid = tq;
+        const int cA = tid >> 4, pA = tid & 15, cB = tid >> 5, pB = tid & 31;
+        const int jA = 32 * w + cA, jB = 16 * w + cB;
         const unsigned epoch = (unsigned)(p.s1 - s);
         unsigned so[2] = {(unsigned)(rw[0] * S + s), (unsigned)(rw[1] * S + s)};
         asm volatile("" : "+v"(so[0]), "+v"(so[1]));   // opaque per-step offsets: no precomputed 64-bit addresses kept live
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 e = fmaf(mv.x, gv.x, e); e = fmaf(mv.y, gv.y, e); e = fmaf(mv.z, gv.z, e); e = fmaf(mv.w, gv.w, e);
             }
             e = dpp_add<0xB1>(e);
-            if (half == 0) put_g(xDA + (long)w * 2 * Ti + i, epoch, e);
+            if (half == 0) put_gi(xDA, (unsigned)(w * 2 * Ti + i), epoch, e);
             float val[4];
             const u64* ptr[4];
 #pragma unroll
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
 #pragma unroll
             for (int tp = 0; tp < 8; ++tp) x += cp_l[tp * 64 + tid];
             dq_l[row * PLEN(256) + PIDX(j)] = x;
-            put_g(xDQ + row * 256 + j, epoch, x);
+            put_gi(xDQ, (unsigned)(row * 256 + j), epoch, x);
             if (ok[row]) p.dq[so[row] * 256 + j] = x;
         }
         gather_vec<32>(xDQ, dq_l, dq_l + PLEN(256), w, epoch, tid, p.err);
@@ -667,7 +681,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     dhd[b] = dhT[b] * u_[b];
                     const float dcp = dhT[b] * (1.f - u_[b]) * (1.f - c_[b] * c_[b]);
                     dxp_l[b * PLEN(768) + PIDX(512 + jA)] = dcp;
-                    put_g(xDCP + b * 256 + jA, epoch, dcp);
+                    put_gi(xDCP, (unsigned)(b * 256 + jA), epoch, dcp);
                     if (ok[b]) p.dxp[so[b] * 768 + 512 + jA] = dcp;
                 }
             }
@@ -689,8 +703,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     dhp[b] = dhd[b] + drh[b] * r_[b];
                     dxp_l[b * PLEN(768) + PIDX(jA)] = dgr;
                     dxp_l[b * PLEN(768) + PIDX(256 + jA)] = dgu;
-                    put_g(xDGR + b * 256 + jA, epoch, dgr);
-                    put_g(xDGU + b * 256 + jA, epoch, dgu);
+                    put_gi(xDGR, (unsigned)(b * 256 + jA), epoch, dgr);
+                    put_gi(xDGU, (unsigned)(b * 256 + jA), epoch, dgu);
                     if (ok[b]) { p.dxp[so[b] * 768 + jA] = dgr; p.dxp[so[b] * 768 + 256 + jA] = dgu; }
                 }
             }
@@ -724,7 +738,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             if (pB == 0) {
                 b0 = p2v[0] > 0.f ? b0 : 0.f; b1 = p2v[1] > 0.f ? b1 : 0.f;
                 dp2_l[PIDX(jB)] = b0; dp2_l[PLEN(128) + PIDX(jB)] = b1;
-                put_g(xDP2 + jB, epoch, b0); put_g(xDP2 + 128 + jB, epoch, b1);
+                put_gi(xDP2, (unsigned)(jB), epoch, b0); put_gi(xDP2, (unsigned)(128 + jB), epoch, b1);
                 if (ok[0]) p.dp2[so[0] * 128 + jB] = b0;
                 if (ok[1]) p.dp2[so[1] * 128 + jB] = b1;
             }
@@ -740,7 +754,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             if (pA == 0) {
                 a0 = p1v[0] > 0.f ? a0 : 0.f; a1 = p1v[1] > 0.f ? a1 : 0.f;
                 dp1_l[PIDX(jA)] = a0; dp1_l[PLEN(256) + PIDX(jA)] = a1;
-                put_g(xDP1 + jA, epoch, a0); put_g(xDP1 + 256 + jA, epoch, a1);
+                put_gi(xDP1, (unsigned)(jA), epoch, a0); put_gi(xDP1, (unsigned)(256 + jA), epoch, a1);
                 if (ok[0]) p.dp1[so[0] * 256 + jA] = a0;
                 if (ok[1]) p.dp1[so[1] * 256 + jA] = a1;
             }
