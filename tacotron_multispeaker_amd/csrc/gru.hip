@@ -17,6 +17,12 @@
 #include "common.hpp"
 
 #define H 128
+typedef float f2 __attribute__((ext_vector_type(2)));
+// 4-term slice of a dot product as two v_pk_fma_f32 (packed fp32 issues two FMAs per lane per instruction)
+__device__ __forceinline__ void pk_dot4(const float4& v, const f2* w2, f2& acc) {
+    acc = __builtin_elementwise_fma((f2){v.x, v.y}, w2[0], acc);
+    acc = __builtin_elementwise_fma((f2){v.z, v.w}, w2[1], acc);
+}
 #define GT 512
 #define LIDX(k) ((k) + ((k) >> 5) * 4)      // 4 pad floats after every 32
 #define LLEN(n) ((n) + ((n) >> 5) * 4)
@@ -48,14 +54,14 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
 
     const int gcol = tid >> 1, kh = tid & 1;        // gates: 256 columns x 2 K-halves
     const int ccol = tid >> 2, kq = tid & 3;        // candidate: 128 columns x 4 K-quarters
-    float wg[64], wc[32];
+    f2 wg[32], wc[16];
     {
         const float* Wg = p.wg[dir];
         const float* Wc = p.wc[dir];
 #pragma unroll
-        for (int k = 0; k < 64; ++k) wg[k] = Wg[(kh * 64 + k) * 256 + gcol];
+        for (int k = 0; k < 32; ++k) wg[k] = (f2){Wg[(kh * 64 + 2 * k) * 256 + gcol], Wg[(kh * 64 + 2 * k + 1) * 256 + gcol]};
 #pragma unroll
-        for (int k = 0; k < 32; ++k) wc[k] = Wc[(kq * 32 + k) * H + ccol];
+        for (int k = 0; k < 16; ++k) wc[k] = (f2){Wc[(kq * 32 + 2 * k) * H + ccol], Wc[(kq * 32 + 2 * k + 1) * H + ccol]};
     }
     const int len = p.lengths ? min(max(p.lengths[row], 0), p.T) : p.T;
     for (int i = tid; i < LLEN(H); i += GT) { h_l[i] = 0.0f; rh_l[i] = 0.0f; }
@@ -82,15 +88,13 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
             if (kq == 0) xc = xrow[(long)tn * p.ldxp + 2 * H + ccol];
         }
         // ---- gates
-        float a = 0.0f;
+        float a;
         {
             const float* hp = h_l + LIDX(kh * 64);
+            f2 a2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int k4 = 0; k4 < 16; ++k4) {
-                const float4 v = *reinterpret_cast<const float4*>(hp + LIDX(k4 * 4));
-                a = fmaf(v.x, wg[k4 * 4], a); a = fmaf(v.y, wg[k4 * 4 + 1], a);
-                a = fmaf(v.z, wg[k4 * 4 + 2], a); a = fmaf(v.w, wg[k4 * 4 + 3], a);
-            }
+            for (int k4 = 0; k4 < 16; ++k4) pk_dot4(*reinterpret_cast<const float4*>(hp + LIDX(k4 * 4)), wg + 2 * k4, a2);
+            a = a2.x + a2.y;
         }
         a = group_sum<2>(a);
         if (kh == 0) {
@@ -101,15 +105,13 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
         }
         __syncthreads();
         // ---- candidate + state update
-        float b = 0.0f;
+        float b;
         {
             const float* qp = rh_l + LIDX(kq * 32);
+            f2 b2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                const float4 v = *reinterpret_cast<const float4*>(qp + k4 * 4);
-                b = fmaf(v.x, wc[k4 * 4], b); b = fmaf(v.y, wc[k4 * 4 + 1], b);
-                b = fmaf(v.z, wc[k4 * 4 + 2], b); b = fmaf(v.w, wc[k4 * 4 + 3], b);
-            }
+            for (int k4 = 0; k4 < 8; ++k4) pk_dot4(*reinterpret_cast<const float4*>(qp + k4 * 4), wc + 2 * k4, b2);
+            b = b2.x + b2.y;
         }
         b = group_sum<4>(b);
         if (kq == 0) {
@@ -135,19 +137,19 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
     __shared__ __attribute__((aligned(16))) float dcp_l[LLEN(H)];
     __shared__ __attribute__((aligned(16))) float dg_l[LLEN(2 * H)];
 
-    float wcT[32], wgT[64];
+    f2 wcT[16], wgT[32];
     {
         const float* Wg = p.wg[dir];
         const float* Wc = p.wc[dir];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float4 a = *reinterpret_cast<const float4*>(Wc + k * H + jq * 32 + q * 4);
-            wcT[q * 4] = a.x; wcT[q * 4 + 1] = a.y; wcT[q * 4 + 2] = a.z; wcT[q * 4 + 3] = a.w;
+            wcT[q * 2] = (f2){a.x, a.y}; wcT[q * 2 + 1] = (f2){a.z, a.w};
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float4 g = *reinterpret_cast<const float4*>(Wg + k * 256 + jq * 64 + q * 4);
-            wgT[q * 4] = g.x; wgT[q * 4 + 1] = g.y; wgT[q * 4 + 2] = g.z; wgT[q * 4 + 3] = g.w;
+            wgT[q * 2] = (f2){g.x, g.y}; wgT[q * 2 + 1] = (f2){g.z, g.w};
         }
     }
     const int len = p.lengths ? min(max(p.lengths[row], 0), p.T) : p.T;
@@ -161,33 +163,41 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
     float* rhrow = p.rh + dn * p.T * H;
     float dh = 0.0f;
     const bool owner = jq == 0;
+    // saved activations / incoming gradient of a step do not depend on the recurrence: fetched ONE STEP AHEAD into
+    // registers so that their HBM/L2 latency is off the dependent chain
+    float pf_r = 0.f, pf_u = 0.f, pf_c = 0.f, pf_h = 0.f, pf_d = 0.f;
+    auto prefetch = [&](int s) {
+        const int t = dir == 0 ? p.T - 1 - s : s;
+        pf_r = pf_u = pf_c = pf_h = pf_d = 0.f;
+        if (owner && t < len) {
+            const float* q = ruc + (long)t * 3 * H;
+            pf_r = q[k]; pf_u = q[H + k]; pf_c = q[2 * H + k];
+            const int tp = dir == 0 ? t - 1 : t + 1;       // forward-order predecessor
+            if (tp >= 0 && tp < len) pf_h = orow[(long)tp * p.ldo + k];
+            pf_d = dorow[(long)t * p.lddo + k];
+        }
+    };
+    prefetch(0);
 
     for (int s = 0; s < p.T; ++s) {
         const int t = dir == 0 ? p.T - 1 - s : s;          // reverse of the forward order
         const bool valid = t < len;
-        float r = 0.f, u = 0.f, c = 0.f, hprev = 0.f, dhT = 0.f;
-        if (owner && valid) {
-            const float* q = ruc + (long)t * 3 * H;
-            r = q[k]; u = q[H + k]; c = q[2 * H + k];
-            const int tp = dir == 0 ? t - 1 : t + 1;       // forward-order predecessor
-            if (tp >= 0 && tp < len) hprev = orow[(long)tp * p.ldo + k];
-            dhT = dh + dorow[(long)t * p.lddo + k];
-        }
+        const float r = pf_r, u = pf_u, c = pf_c, hprev = pf_h;
+        const float dhT = (owner && valid) ? dh + pf_d : 0.f;
+        if (s + 1 < p.T) prefetch(s + 1);
         const float du = dhT * (hprev - c);
         float dh_new = valid ? dhT * u : dh;
         const float dcp = dhT * (1.0f - u) * (1.0f - c * c);
         if (owner) dcp_l[LIDX(k)] = dcp;
         __syncthreads();
         // ---- drh[k] = sum_j dcp[j] * Wc[k][j]
-        float drh = 0.0f;
+        float drh;
         {
             const float* a = dcp_l + LIDX(jq * 32);
+            f2 d2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(a + q * 4);
-                drh = fmaf(v.x, wcT[q * 4], drh); drh = fmaf(v.y, wcT[q * 4 + 1], drh);
-                drh = fmaf(v.z, wcT[q * 4 + 2], drh); drh = fmaf(v.w, wcT[q * 4 + 3], drh);
-            }
+            for (int q = 0; q < 8; ++q) pk_dot4(*reinterpret_cast<const float4*>(a + q * 4), wcT + 2 * q, d2);
+            drh = d2.x + d2.y;
         }
         drh = group_sum<4>(drh);
         if (owner) {
@@ -203,15 +213,13 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
         }
         __syncthreads();
         // ---- dh_{prev}[k] += sum_j dg[j] * Wg[k][j]   (j over 256, quarter of 64 per lane)
-        float e = 0.0f;
+        float e;
         {
             const float* a = dg_l + LIDX(jq * 64);
+            f2 e2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(a + LIDX(q * 4));
-                e = fmaf(v.x, wgT[q * 4], e); e = fmaf(v.y, wgT[q * 4 + 1], e);
-                e = fmaf(v.z, wgT[q * 4 + 2], e); e = fmaf(v.w, wgT[q * 4 + 3], e);
-            }
+            for (int q = 0; q < 16; ++q) pk_dot4(*reinterpret_cast<const float4*>(a + LIDX(q * 4)), wgT + 2 * q, e2);
+            e = e2.x + e2.y;
         }
         e = group_sum<4>(e);
         dh = dh_new + e;

@@ -357,8 +357,12 @@ class Engine:
         k = k or self.pipe_chunks
         if k <= 1 or S < 2 * k or not lib.load().taco_attn_cluster_supported(N, Ti):
             return [(0, S)]
-        step = (S + k - 1) // k
-        return [(s, min(S, s + step)) for s in range(0, S, step)]
+        # The last chunk is half as long as the others: GRU1/GRU2 of the last chunk run after the attention recurrence has
+        # finished (forward), and GRU2/GRU1 of the last chunk run before the attention BPTT can start (backward).
+        last = max(1, S // (2 * k))
+        step = (S - last + k - 2) // (k - 1)
+        bounds = [min(S - last, i * step) for i in range(k)] + [S]
+        return [(bounds[i], bounds[i + 1]) for i in range(k) if bounds[i + 1] > bounds[i]]
 
     def _dims(self, N, S, Ti, s0, s1):
         return (ctypes.c_int * 5)(N, S, Ti, s0, s1)
