@@ -63,6 +63,7 @@ __device__ __forceinline__ void get_g(const u64* const (&ptr)[NG], unsigned epoc
 template <int KPER>
 __device__ __forceinline__ void dot2(const float* __restrict__ v0, const float* __restrict__ v1, int kbase,
                                      const float (&w)[KPER], float& a0, float& a1) {
+    f2 p0 = {a0, 0.0f}, p1 = {a1, 0.0f};
 #pragma unroll
     for (int k4 = 0; k4 < KPER / 4; ++k4) {
         // keep at most 4 LDS vectors in flight: hoisting every ds_read of a 32-deep part ahead of the FMAs costs
@@ -71,16 +72,15 @@ __device__ __forceinline__ void dot2(const float* __restrict__ v0, const float* 
         const int k = kbase + k4 * 4;
         const float4 x0 = *reinterpret_cast<const float4*>(v0 + PIDX(k));
         const float4 x1 = *reinterpret_cast<const float4*>(v1 + PIDX(k));
-        a0 = fmaf(x0.x, w[k4 * 4], a0); a1 = fmaf(x1.x, w[k4 * 4], a1);
-        a0 = fmaf(x0.y, w[k4 * 4 + 1], a0); a1 = fmaf(x1.y, w[k4 * 4 + 1], a1);
-        a0 = fmaf(x0.z, w[k4 * 4 + 2], a0); a1 = fmaf(x1.z, w[k4 * 4 + 2], a1);
-        a0 = fmaf(x0.w, w[k4 * 4 + 3], a0); a1 = fmaf(x1.w, w[k4 * 4 + 3], a1);
+        pk_dot4x2(x0, x1, w[k4 * 4], w[k4 * 4 + 1], w[k4 * 4 + 2], w[k4 * 4 + 3], p0, p1);
     }
+    a0 = p0.x + p0.y; a1 = p1.x + p1.y;
 }
 // same, weights parked in LDS as per-thread float4 slots wl[(k4 * AT + tid) * 4 ..] (conflict-free b128 reads)
 template <int KPER>
 __device__ __forceinline__ void dot2_lds(const float* __restrict__ v0, const float* __restrict__ v1, int kbase,
                                          const float* __restrict__ wl, int tid, float& a0, float& a1) {
+    f2 p0 = {a0, 0.0f}, p1 = {a1, 0.0f};
 #pragma unroll
     for (int k4 = 0; k4 < KPER / 4; ++k4) {
         if (k4 && (k4 & 1) == 0) asm volatile("" ::: "memory");
@@ -88,11 +88,9 @@ __device__ __forceinline__ void dot2_lds(const float* __restrict__ v0, const flo
         const float4 x0 = *reinterpret_cast<const float4*>(v0 + PIDX(k));
         const float4 x1 = *reinterpret_cast<const float4*>(v1 + PIDX(k));
         const float4 wv = *reinterpret_cast<const float4*>(wl + (k4 * AT + tid) * 4);
-        a0 = fmaf(x0.x, wv.x, a0); a1 = fmaf(x1.x, wv.x, a1);
-        a0 = fmaf(x0.y, wv.y, a0); a1 = fmaf(x1.y, wv.y, a1);
-        a0 = fmaf(x0.z, wv.z, a0); a1 = fmaf(x1.z, wv.z, a1);
-        a0 = fmaf(x0.w, wv.w, a0); a1 = fmaf(x1.w, wv.w, a1);
+        pk_dot4x2(x0, x1, wv.x, wv.y, wv.z, wv.w, p0, p1);
     }
+    a0 = p0.x + p0.y; a1 = p1.x + p1.y;
 }
 template <int PARTS>
 __device__ __forceinline__ float lane_reduce(float v) { return group_sum<PARTS>(v); }

@@ -5,6 +5,14 @@
 #include "../../include/taco_hip.h"   // prototypes are checked against the definitions
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+// 4 reduction terms of two rows that share the weights (w0..w3) as four v_pk_fma_f32: packed fp32 issues two FMAs per
+// lane per instruction, which halves the VALU issue time of the register-resident recurrent matvecs
+__device__ __forceinline__ void pk_dot4x2(const float4& v0, const float4& v1, float w0, float w1, float w2, float w3, f2& a0, f2& a1) {
+    const f2 wa = {w0, w1}, wb = {w2, w3};
+    a0 = __builtin_elementwise_fma((f2){v0.x, v0.y}, wa, a0); a0 = __builtin_elementwise_fma((f2){v0.z, v0.w}, wb, a0);
+    a1 = __builtin_elementwise_fma((f2){v1.x, v1.y}, wa, a1); a1 = __builtin_elementwise_fma((f2){v1.z, v1.w}, wb, a1);
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TACO_OK 0

@@ -17,7 +17,6 @@
 #include "common.hpp"
 
 #define H 128
-typedef float f2 __attribute__((ext_vector_type(2)));
 // 4-term slice of a dot product as two v_pk_fma_f32 (packed fp32 issues two FMAs per lane per instruction)
 __device__ __forceinline__ void pk_dot4(const float4& v, const f2* w2, f2& acc) {
     acc = __builtin_elementwise_fma((f2){v.x, v.y}, w2[0], acc);

@@ -128,8 +128,9 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
             if (k8 == 0) { nxc0 = p.xp[(o0 + 1u) * 768u + 512u + jc]; nxc1 = p.xp[(o1 + 1u) * 768u + 512u + jc]; }
         }
         // ---- gates (both rows), K quarter per lane
-        float a0 = 0.0f, a1 = 0.0f;
+        float a0, a1;
         {
+            f2 a0p = {0.0f, 0.0f}, a1p = {0.0f, 0.0f};
             const float* h0 = &h_l[0][QIDX(kq * 64)];
             const float* h1 = &h_l[1][QIDX(kq * 64)];
 #pragma unroll
@@ -137,11 +138,9 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
                 if (k4 && (k4 & 3) == 0) asm volatile("" ::: "memory");
                 const float4 v0 = *reinterpret_cast<const float4*>(h0 + QIDX(k4 * 4));
                 const float4 v1 = *reinterpret_cast<const float4*>(h1 + QIDX(k4 * 4));
-                a0 = fmaf(v0.x, wg[k4 * 4], a0); a1 = fmaf(v1.x, wg[k4 * 4], a1);
-                a0 = fmaf(v0.y, wg[k4 * 4 + 1], a0); a1 = fmaf(v1.y, wg[k4 * 4 + 1], a1);
-                a0 = fmaf(v0.z, wg[k4 * 4 + 2], a0); a1 = fmaf(v1.z, wg[k4 * 4 + 2], a1);
-                a0 = fmaf(v0.w, wg[k4 * 4 + 3], a0); a1 = fmaf(v1.w, wg[k4 * 4 + 3], a1);
+                pk_dot4x2(v0, v1, wg[k4 * 4], wg[k4 * 4 + 1], wg[k4 * 4 + 2], wg[k4 * 4 + 3], a0p, a1p);
             }
+            a0 = a0p.x + a0p.y; a1 = a1p.x + a1p.y;
         }
         a0 = group_sum<4>(a0);
         a1 = group_sum<4>(a1);
@@ -164,19 +163,18 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
         gather256(xr, rh_l[0], rh_l[1], 0, w, epoch, tid, p.err);
         __syncthreads();
         // ---- candidate + state for hidden index jc (both rows), K eighth per lane
-        float c0 = 0.0f, c1 = 0.0f;
+        float c0, c1;
         {
+            f2 c0p = {0.0f, 0.0f}, c1p = {0.0f, 0.0f};
             const float* q0p = &rh_l[0][QIDX(k8 * 32)];
             const float* q1p = &rh_l[1][QIDX(k8 * 32)];
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4) {
                 const float4 v0 = *reinterpret_cast<const float4*>(q0p + k4 * 4);
                 const float4 v1 = *reinterpret_cast<const float4*>(q1p + k4 * 4);
-                c0 = fmaf(v0.x, wc[k4 * 4], c0); c1 = fmaf(v1.x, wc[k4 * 4], c1);
-                c0 = fmaf(v0.y, wc[k4 * 4 + 1], c0); c1 = fmaf(v1.y, wc[k4 * 4 + 1], c1);
-                c0 = fmaf(v0.z, wc[k4 * 4 + 2], c0); c1 = fmaf(v1.z, wc[k4 * 4 + 2], c1);
-                c0 = fmaf(v0.w, wc[k4 * 4 + 3], c0); c1 = fmaf(v1.w, wc[k4 * 4 + 3], c1);
+                pk_dot4x2(v0, v1, wc[k4 * 4], wc[k4 * 4 + 1], wc[k4 * 4 + 2], wc[k4 * 4 + 3], c0p, c1p);
             }
+            c0 = c0p.x + c0p.y; c1 = c1p.x + c1p.y;
         }
         c0 = group_sum<8>(c0); c1 = group_sum<8>(c1);
         if (k8 == 0) {
@@ -282,19 +280,18 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
         gather256(xc, dx_l[0], dx_l[1], 512, w, epoch, tid, p.err);
         __syncthreads();
         // ---- drh[k_own] = sum_j dcp[j] * Whc[k_own][j]  (eighth per lane, both rows)
-        float d0 = 0.0f, d1 = 0.0f;
+        float d0, d1;
         {
+            f2 d0p = {0.0f, 0.0f}, d1p = {0.0f, 0.0f};
             const float* a0 = &dx_l[0][QIDX(512 + j8 * 32)];
             const float* a1 = &dx_l[1][QIDX(512 + j8 * 32)];
 #pragma unroll
             for (int j4 = 0; j4 < 8; ++j4) {
                 const float4 v0 = *reinterpret_cast<const float4*>(a0 + j4 * 4);
                 const float4 v1 = *reinterpret_cast<const float4*>(a1 + j4 * 4);
-                d0 = fmaf(v0.x, wcT[j4 * 4], d0); d1 = fmaf(v1.x, wcT[j4 * 4], d1);
-                d0 = fmaf(v0.y, wcT[j4 * 4 + 1], d0); d1 = fmaf(v1.y, wcT[j4 * 4 + 1], d1);
-                d0 = fmaf(v0.z, wcT[j4 * 4 + 2], d0); d1 = fmaf(v1.z, wcT[j4 * 4 + 2], d1);
-                d0 = fmaf(v0.w, wcT[j4 * 4 + 3], d0); d1 = fmaf(v1.w, wcT[j4 * 4 + 3], d1);
+                pk_dot4x2(v0, v1, wcT[j4 * 4], wcT[j4 * 4 + 1], wcT[j4 * 4 + 2], wcT[j4 * 4 + 3], d0p, d1p);
             }
+            d0 = d0p.x + d0p.y; d1 = d1p.x + d1p.y;
         }
         d0 = group_sum<8>(d0); d1 = group_sum<8>(d1);
         float dhp[2] = {0.f, 0.f};
@@ -329,8 +326,9 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
         }
         __syncthreads();
         // ---- dh_{s-1}[k_own] = dhp + sum_j dg[j] * Whg[k_own][j]   (j over 512, eighth of 64 per lane)
-        float e0 = 0.0f, e1 = 0.0f;
+        float e0, e1;
         {
+            f2 e0p = {0.0f, 0.0f}, e1p = {0.0f, 0.0f};
             const float* a0 = &dx_l[0][QIDX(j8 * 64)];
             const float* a1 = &dx_l[1][QIDX(j8 * 64)];
 #pragma unroll
@@ -338,11 +336,9 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
                 if (j4 && (j4 & 3) == 0) asm volatile("" ::: "memory");
                 const float4 v0 = *reinterpret_cast<const float4*>(a0 + QIDX(j4 * 4));
                 const float4 v1 = *reinterpret_cast<const float4*>(a1 + QIDX(j4 * 4));
-                e0 = fmaf(v0.x, wgT[j4 * 4], e0); e1 = fmaf(v1.x, wgT[j4 * 4], e1);
-                e0 = fmaf(v0.y, wgT[j4 * 4 + 1], e0); e1 = fmaf(v1.y, wgT[j4 * 4 + 1], e1);
-                e0 = fmaf(v0.z, wgT[j4 * 4 + 2], e0); e1 = fmaf(v1.z, wgT[j4 * 4 + 2], e1);
-                e0 = fmaf(v0.w, wgT[j4 * 4 + 3], e0); e1 = fmaf(v1.w, wgT[j4 * 4 + 3], e1);
+                pk_dot4x2(v0, v1, wgT[j4 * 4], wgT[j4 * 4 + 1], wgT[j4 * 4 + 2], wgT[j4 * 4 + 3], e0p, e1p);
             }
+            e0 = e0p.x + e0p.y; e1 = e1p.x + e1p.y;
         }
         e0 = group_sum<8>(e0); e1 = group_sum<8>(e1);
         if (owner) { dhn[0] = dhp[0] + e0; dhn[1] = dhp[1] + e1; dhT[0] = dhn[0] + don[0]; dhT[1] = dhn[1] + don[1]; }
