@@ -503,14 +503,11 @@ class Engine:
         car = {g: self.buf('gcarry%d' % g, N, 256) for g in (1, 2)}
         xg = {g: b['xchg_g%d' % g] for g in (1, 2)}
         Wp = self.P('concat_projection/kernel')
-        first = True
-        for (s0, s1) in chunks:
+        flush_at = min(len(chunks) - 1, int(os.environ.get('TACO_FLUSH_AT', '99')))
+        for ci, (s0, s1) in enumerate(chunks):
             R, U, C, RH, Hh = (b['g2_%s' % k] for k in ('r', 'u', 'c', 'rh', 'h'))
             lib.taco_gru256_seq_bwd(dD, self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), R, U, C, Hh, dxp[2], car[2],
                                     xg[2], self.err, N, S, s0, s1, self.st)
-            if first:
-                self.flush_side()          # post-net weight gradients fill the CUs the recurrences leave idle
-                first = False
             ev = torch.cuda.Event(); ev.record(cur)
             sb.wait_event(ev)
             with torch.cuda.stream(sb):
@@ -524,6 +521,10 @@ class Engine:
                 self.dense_rows_dx(dxp[1], self.P('decoder_gru_1/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dY = dD1 + dxp1.Wx1^T
                 self.dense_rows_dx(dD, Wp, dHC, N, S, s0, s1, 512, 256, 256, 512, 0)                               # d[h|ctx] = dY.Wp^T
                 lib.taco_attn_rnn_bwd(self._attn_ptrs, self._dims(N, S, Ti, s0, s1), self.st)
+            if ci == flush_at:
+                # post-net weight gradients fill the CUs the recurrences leave idle; released once the GRU BPTT chunks
+                # (which crowd the first attention chunks) are mostly done
+                self.flush_side()
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
         dY = dD
