@@ -86,6 +86,14 @@ int taco_add(const float* a, const float* b, float* y, long n, int accumulate, h
 int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2, long rows,
                  int C, int npri, float w_all, float w_pri, hipStream_t stream);
 
+/* ---- optional alignment regularisers (models/tacotron.py:140-171; hparams overwrought / oneorder_dynamic /
+ * variance_between_row / alignment_entropy, all 0.0 by default).  align [N,S,Ti] (the layout the attention kernels save;
+ * the reference tensor is its [N,Ti,S] transpose).  Adds the regulariser value to loss_sum[0] and WRITES its gradient wrt
+ * the alignments to dalign [N,S,Ti], which taco_attn_rnn_bwd consumes through TACO_AP_DAEXT.  The reference applies a second
+ * softmax over the decoder-step axis to the alignments (:142); `overwrought` needs S >= 40 (tf.slice at :159). */
+int taco_align_regularity(const float* align, float* dalign, double* loss_sum, int N, int S, int Ti, float overwrought,
+                          float oneorder_dynamic, float variance_between_row, float alignment_entropy, hipStream_t stream);
+
 /* ---- persistent (bi)GRU(128) sequence kernels: tf.nn.bidirectional_dynamic_rnn (models/modules.py:68-74) -------
  * xp [N,T,ldxp]: hoisted x.W_x + b per direction d at columns [d*384, d*384+384) ordered r|u|c;
  * wg [128,256], wc [128,128]: recurrent halves of the GRUCell gates/candidate kernels;
@@ -167,6 +175,7 @@ enum TacoAttnPtr {
     TACO_AP_ERR,       /* optional: device int, set to 1 if a bounded hand-off spin timed out */
     TACO_AP_DE,        /* cluster bwd: out, softmax-input gradients de_s[t]           [N,S,Ti] */
     TACO_AP_DCTXS,     /* cluster bwd: out, total context gradients per step          [N,S,256] */
+    TACO_AP_DAEXT,     /* optional in: extra gradient wrt the alignments (taco_align_regularity) [N,S,Ti]; may be NULL */
     TACO_AP_COUNT
 };
 

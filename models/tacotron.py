@@ -145,14 +145,14 @@ class Tacotron():
     def add_loss(self):
         '''Adds loss to the model. Sets "loss" field. initialize must have been called (reference :127-171).'''
         hp = self._hparams
-        if hp.overwrought or hp.oneorder_dynamic or hp.variance_between_row or hp.alignment_entropy:
-            raise NotImplementedError('alignment regularisers (tacotron.py:140-171) are off by default in the reference '
-                                      'and not built yet (SURVEY.md 8(f) row f4)')
+        # loss_regularity (reference :140-171): computed on the GPU together with its gradient wrt the alignments
+        self.engine.set_regularity(hp.overwrought, hp.oneorder_dynamic, hp.variance_between_row, hp.alignment_entropy)
         self.loss_regularity = 0.0
         self.mel_loss = self.linear_loss = self.loss = None
         if self._feeder is None and self._static[3] is not None:
             self.engine.loss(self._static[3], with_grad=False)
             self.loss, self.mel_loss, self.linear_loss = self.engine.loss_values()
+            self.loss_regularity = self.engine.loss_regularity
 
     def add_optimizer(self, global_step):
         '''Adds optimizer. Sets "gradients" and "optimize" fields (reference :174-195).'''
@@ -184,6 +184,7 @@ class Tacotron():
         e.train_step(s[0], s[1], s[2], s[3], s[4])
         self.mel_outputs, self.linear_outputs, self.alignments = e.mel_outputs, e.linear_outputs, e.alignments
         self.loss, self.mel_loss, self.linear_loss = e.loss_values()
+        self.loss_regularity = e.loss_regularity
         step = int(e.global_step.item())
         self.learning_rate = float(e.info[1].item())
         return step, self.loss, None, self.loss_regularity

@@ -361,12 +361,40 @@ def n_priority_freq(sample_rate=20000, num_freq=1025):
 
 
 def loss(mel_out, lin_out, mel_targets, linear_targets, sample_rate=20000):
-    """tacotron.py:127-137 (regularisers :140-171 have default weight 0.0 and are not built)."""
+    """tacotron.py:127-137 (the optional regularisers :140-171 are alignment_regularity below)."""
     mel_loss = np.abs(mel_targets - mel_out).mean()
     l1 = np.abs(linear_targets - lin_out)
     npf = n_priority_freq(sample_rate, lin_out.shape[-1])
     linear_loss = 0.5 * l1.mean() + 0.5 * l1[:, :, :npf].mean()
     return mel_loss + linear_loss, mel_loss, linear_loss
+
+
+def alignment_regularity(alignments, overwrought=0.0, oneorder_dynamic=0.0, variance_between_row=0.0,
+                         alignment_entropy=0.0):
+    """loss_regularity of tacotron.py:140-171 (all weights default to 0.0 in hparams.py:74-77 of the reference).
+    alignments: [N, T_in, S] as returned by the model (tacotron.py:104).  NB the reference applies a SECOND softmax over
+    the decoder-step axis (:142) to the already normalised alignments; pr_slice_last_word (:158) is computed but unused."""
+    a = np.asarray(alignments, np.float64)
+    N, Ti, S = a.shape
+    reg = 0.0
+    if overwrought or oneorder_dynamic or variance_between_row or alignment_entropy:
+        e = np.exp(a - a.max(axis=2, keepdims=True))
+        pr = e / e.sum(axis=2, keepdims=True)
+        if alignment_entropy:
+            reg += -1.0 * alignment_entropy * np.mean(pr * np.log(pr))
+        if oneorder_dynamic:
+            reg += oneorder_dynamic * np.abs(pr[:, :, :-1] - pr[:, :, 1:]).sum()
+        if overwrought:
+            size = S - 41                                   # tf.slice(pr, [0,0,40], [N,1,S-41]); -1 = "to the end"
+            if size < -1 or S < 40:
+                raise ValueError('overwrought regulariser needs at least 40 decoder steps (tf.slice at tacotron.py:159)')
+            end = S if size == -1 else 40 + size
+            reg += overwrought * pr[:, 0:1, 40:end].sum()
+        if variance_between_row:
+            sum_row = a.sum(axis=2)
+            mean_row = sum_row.mean(axis=1, keepdims=True)
+            reg += variance_between_row * ((mean_row - sum_row) ** 2).sum()
+    return reg
 
 
 def noam_lr(init_lr, global_step):

@@ -171,6 +171,31 @@ def loss_fn(mel_out, lin_out, mel_targets, linear_targets, sample_rate=20000):
     return mel_loss + linear_loss, mel_loss, linear_loss
 
 
+def alignment_regularity(alignments, overwrought=0.0, oneorder_dynamic=0.0, variance_between_row=0.0,
+                         alignment_entropy=0.0):
+    """tacotron.py:140-171 on alignments [N, T_in, S] (second softmax over the decoder-step axis, :142)."""
+    a = alignments
+    S = a.shape[2]
+    reg = a.new_zeros(())
+    if overwrought or oneorder_dynamic or variance_between_row or alignment_entropy:
+        pr = torch.softmax(a, dim=2)
+        if alignment_entropy:
+            reg = reg - alignment_entropy * (pr * pr.log()).mean()
+        if oneorder_dynamic:
+            reg = reg + oneorder_dynamic * (pr[:, :, :-1] - pr[:, :, 1:]).abs().sum()
+        if overwrought:
+            size = S - 41
+            if size < -1 or S < 40:
+                raise ValueError('overwrought regulariser needs at least 40 decoder steps (tf.slice at tacotron.py:159)')
+            end = S if size == -1 else 40 + size
+            reg = reg + overwrought * pr[:, 0:1, 40:end].sum()
+        if variance_between_row:
+            sum_row = a.sum(dim=2)
+            mean_row = sum_row.mean(dim=1, keepdim=True)
+            reg = reg + variance_between_row * ((mean_row - sum_row) ** 2).sum()
+    return reg
+
+
 def noam_lr(init_lr, global_step):
     """tacotron.py:198-202."""
     step = float(global_step + 1)
@@ -181,13 +206,14 @@ class TrainState:
     """Parameters + Adam slots + global_step; one .step(batch) == one sess.run of train.py:142-146."""
 
     def __init__(self, P_np, dtype=torch.float64, id_num=0, r=5, init_lr=0.002, decay=True,
-                 beta1=0.9, beta2=0.999, tf_sparse_norm=True, sample_rate=20000):
+                 beta1=0.9, beta2=0.999, tf_sparse_norm=True, sample_rate=20000, regularity=None):
         self.P = to_torch(P_np, dtype)
         self.dtype = dtype
         self.id_num, self.r = id_num, r
         self.init_lr, self.decay, self.beta1, self.beta2 = init_lr, decay, beta1, beta2
         self.tf_sparse_norm = tf_sparse_norm
         self.sample_rate = sample_rate
+        self.regularity = dict(regularity or {})      # overwrought / oneorder_dynamic / variance_between_row / alignment_entropy
         self.global_step = 0
         self.M = {k: torch.zeros_like(v) for k, v in self.P.items() if v.requires_grad}
         self.V = {k: torch.zeros_like(v) for k, v in self.P.items() if v.requires_grad}
@@ -203,6 +229,8 @@ class TrainState:
                       self.id_num, self.r, mel_t.shape[-1], training=True)
         loss, mel_loss, lin_loss = loss_fn(out['mel_outputs'], out['linear_outputs'], mel_t, lin_t,
                                            self.sample_rate)
+        reg = alignment_regularity(out['alignments'], **self.regularity)
+        loss = loss + reg
         loss.backward()
         grads = OrderedDict((k, v.grad if v.grad is not None else torch.zeros_like(v))
                             for k, v in P.items() if v.requires_grad)
@@ -214,7 +242,7 @@ class TrainState:
             sparse['embedding'] = float((eg[:, :, :et] ** 2).sum())
             if 'embedding_id' in P and eg.shape[2] > et:
                 sparse['embedding_id'] = float((eg[:, :, et:].sum(dim=1) ** 2).sum())
-        self.last = dict(out=out, loss=float(loss.detach()), mel_loss=float(mel_loss.detach()), linear_loss=float(lin_loss.detach()),
+        self.last = dict(out=out, loss=float(loss.detach()), loss_regularity=float(reg.detach()), mel_loss=float(mel_loss.detach()), linear_loss=float(lin_loss.detach()),
                          grads=grads, sparse_sumsq=sparse)
         return self.last
 

@@ -628,6 +628,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             const int row = tid >> 6, lane = tid & 63;
             float* dr_ = de_l + row * Ti;
             const float* ar = a_l + row * Ti;
+            if (p.da_ext) {                                       // regulariser gradient wrt a_s (off by default)
+                const float* ex = p.da_ext + so[row] * (unsigned)Ti;
+                for (int t = lane; t < Ti; t += 64) dr_[t] += ex[t];
+            }
             float dot = 0.f;
             for (int t = lane; t < Ti; t += 64) dot = fmaf(ar[t], dr_[t], dot);
             dot = wave_sum_fast(dot);

@@ -12,6 +12,7 @@ int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st);
 struct AttnCluB {
     const float *w1c, *w2, *wx, *whg, *whc, *wq, *v, *keys, *mem;
     const float *p1, *p2, *r, *u, *c, *hc, *q, *align, *dhc;
+    const float* da_ext;             // optional [N,S,Ti]: extra gradient wrt the alignments (regularisers), or nullptr
     float *dxp, *dp2, *dp1, *dq, *de, *dctx;
     float *dhcarry, *dctxcarry;      // [N,256] each: state handed between chunk launches
     u64* xchg; int* err;

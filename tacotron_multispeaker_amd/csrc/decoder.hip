@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_softmax_ctx_k(float* __restrict__ e,
 // backward A1: da[n,t] = dctx[n,:] . mem[n,t,:];  dmem[n,t,:] += a[t] * dctx[n,:]   (one wave per t)
 __global__ __launch_bounds__(256) void attn_bwd_da_k(const float* __restrict__ mem, const float* __restrict__ a, int lda_,
                                                     const float* __restrict__ dctx, int lddc, float* __restrict__ da,
-                                                    float* __restrict__ dmem, int Ti) {
+                                                    float* __restrict__ dmem, int Ti, const float* __restrict__ da_ext, int ldext) {
     const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 g = *reinterpret_cast<const float4*>(dctx + (long)n * lddc + lane * 4);
     const int t0 = blockIdx.y * 16;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_da_k(const float* __restrict__ m
         const long off = ((long)n * Ti + t) * 256 + lane * 4;
         const float4 m = *reinterpret_cast<const float4*>(mem + off);
         float s = wave_sum(g.x * m.x + g.y * m.y + g.z * m.z + g.w * m.w);
-        if (lane == 0) da[(long)n * Ti + t] = s;
+        if (lane == 0) da[(long)n * Ti + t] = s + (da_ext ? da_ext[(long)n * ldext + t] : 0.0f);
         const float at = a[(long)n * lda_ + t];
         float4 dm = *reinterpret_cast<float4*>(dmem + off);
         dm.x = fmaf(at, g.x, dm.x); dm.y = fmaf(at, g.y, dm.y); dm.z = fmaf(at, g.z, dm.z); dm.w = fmaf(at, g.w, dm.w);
@@ -431,7 +431,8 @@ static int attn_rnn_bwd_steps(const void* const* ptrs, const int* dims, hipStrea
         k.o[0] = G(TACO_AP_DCTX); k.ldo[0] = 256;
         launch_skinny(k, st);
         // attention backward
-        hipLaunchKernelGGL(attn_bwd_da_k, gT, dim3(256), 0, st, F(TACO_AP_MEM), al, S * Ti, F(TACO_AP_DCTX), 256, G(TACO_AP_DA), G(TACO_AP_DMEM), Ti);
+        hipLaunchKernelGGL(attn_bwd_da_k, gT, dim3(256), 0, st, F(TACO_AP_MEM), al, S * Ti, F(TACO_AP_DCTX), 256, G(TACO_AP_DA), G(TACO_AP_DMEM), Ti,
+                           ptrs[TACO_AP_DAEXT] ? F(TACO_AP_DAEXT) + (long)s * Ti : nullptr, S * Ti);
         hipLaunchKernelGGL(attn_bwd_score_k, gT, dim3(256), 0, st, F(TACO_AP_KEYS), F(TACO_AP_Q) + (long)s * 256, S * 256, F(TACO_AP_V), al, S * Ti,
                            F(TACO_AP_DA), G(TACO_AP_DKEYS), G(TACO_AP_DQ) + (long)s * 256, S * 256, G(TACO_AP_DVPART), Ti);
         // dhT = dh_ext[s] + carry + dq . Wq^T
@@ -513,6 +514,7 @@ extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipSt
         p.hc = F(TACO_AP_HC); p.q = F(TACO_AP_Q); p.align = F(TACO_AP_ALIGN); p.dhc = F(TACO_AP_DHC);
         p.dxp = G(TACO_AP_DXP); p.dp2 = G(TACO_AP_DP2); p.dp1 = G(TACO_AP_DP1); p.dq = G(TACO_AP_DQ);
         p.de = G(TACO_AP_DE); p.dctx = G(TACO_AP_DCTXS);
+        p.da_ext = ptrs[TACO_AP_DAEXT] ? F(TACO_AP_DAEXT) : nullptr;
         p.xchg = (u64*)const_cast<void*>(ptrs[TACO_AP_XCHG]); p.err = (int*)const_cast<void*>(ptrs[TACO_AP_ERR]);
         p.dhcarry = G(TACO_AP_DHCARRY); p.dctxcarry = G(TACO_AP_DCTXCARRY);
         p.N = N; p.S = S; p.Ti = Ti; p.s0 = dims[3]; p.s1 = dims[4];

@@ -510,6 +510,98 @@ extern "C" int taco_add(const float* a, const float* b, float* y, long n, int ac
     TACO_RETURN_LAST();
 }
 
+// =====================================================================================================
+// Alignment regularisers (models/tacotron.py:140-171).  One workgroup per batch row, thread = encoder position ti (loops
+// for Ti > blockDim); each thread walks its column of S decoder steps (reads are coalesced across ti).
+//   pr = softmax over s of a[n, :, ti];  g = dL/dpr;  dL/da[s] = pr[s] * (g[s] - sum_s' pr[s'] g[s'])  (+ variance term on a)
+// =====================================================================================================
+struct AlignReg { const float* a; float* da; double* loss; int N, S, Ti; float w_over, w_one, w_var, w_ent; };
+
+__global__ __launch_bounds__(256) void align_reg_k(AlignReg p) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* a = p.a + (long)n * p.S * p.Ti;
+    float* da = p.da + (long)n * p.S * p.Ti;
+    const int S = p.S, Ti = p.Ti;
+    __shared__ double red[256];
+    __shared__ float rowmean;
+    // ---- variance_between_row needs mean_ti(sum_s a) first
+    double part = 0.0;
+    for (int ti = tid; ti < Ti; ti += 256) {
+        float r = 0.f;
+        for (int s = 0; s < S; ++s) r += a[(long)s * Ti + ti];
+        part += r;
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) rowmean = (float)(red[0] / Ti);
+    __syncthreads();
+    const float m = rowmean;
+    const bool use_pr = p.w_over != 0.f || p.w_one != 0.f || p.w_ent != 0.f;
+    const float ent_scale = p.w_ent / ((float)p.N * (float)Ti * (float)S);
+    const int over_end = S - 41 == -1 ? S : 40 + (S - 41);           // exclusive end of the tf.slice at :159
+    double loss = 0.0;
+    for (int ti = tid; ti < Ti; ti += 256) {
+        float mx = -3.0e38f, rsum = 0.f;
+        for (int s = 0; s < S; ++s) { const float v = a[(long)s * Ti + ti]; mx = fmaxf(mx, v); rsum += v; }
+        float den = 0.f;
+        if (use_pr) for (int s = 0; s < S; ++s) den += expf(a[(long)s * Ti + ti] - mx);
+        const float inv = use_pr ? 1.0f / den : 0.f;
+        const float dvar = p.w_var * 2.0f * (rsum - m);
+        loss += (double)p.w_var * (double)(m - rsum) * (double)(m - rsum);
+        // pass 1: g and sum pr*g
+        float dot = 0.f, prev = 0.f;
+        if (use_pr) {
+            for (int s = 0; s < S; ++s) {
+                const float pr = expf(a[(long)s * Ti + ti] - mx) * inv;
+                const float nxt = s + 1 < S ? expf(a[(long)(s + 1) * Ti + ti] - mx) * inv : 0.f;
+                float g = 0.f;
+                if (p.w_ent != 0.f) { const float lg = logf(pr); g -= ent_scale * (lg + 1.0f); loss -= (double)ent_scale * pr * lg; }
+                if (p.w_one != 0.f) {
+                    if (s + 1 < S) { const float d = pr - nxt; g += p.w_one * ((d > 0.f) - (d < 0.f)); loss += (double)p.w_one * fabsf(d); }
+                    if (s > 0) { const float d = prev - pr; g -= p.w_one * ((d > 0.f) - (d < 0.f)); }
+                }
+                if (p.w_over != 0.f && ti == 0 && s >= 40 && s < over_end) { g += p.w_over; loss += (double)p.w_over * pr; }
+                dot = fmaf(pr, g, dot);
+                prev = pr;
+            }
+        }
+        // pass 2: gradient wrt a
+        prev = 0.f;
+        for (int s = 0; s < S; ++s) {
+            float out = dvar;
+            if (use_pr) {
+                const float pr = expf(a[(long)s * Ti + ti] - mx) * inv;
+                const float nxt = s + 1 < S ? expf(a[(long)(s + 1) * Ti + ti] - mx) * inv : 0.f;
+                float g = 0.f;
+                if (p.w_ent != 0.f) g -= ent_scale * (logf(pr) + 1.0f);
+                if (p.w_one != 0.f) {
+                    if (s + 1 < S) { const float d = pr - nxt; g += p.w_one * ((d > 0.f) - (d < 0.f)); }
+                    if (s > 0) { const float d = prev - pr; g -= p.w_one * ((d > 0.f) - (d < 0.f)); }
+                }
+                if (p.w_over != 0.f && ti == 0 && s >= 40 && s < over_end) g += p.w_over;
+                out += pr * (g - dot);
+                prev = pr;
+            }
+            da[(long)s * Ti + ti] = out;
+        }
+    }
+    red[tid] = loss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) atomicAdd(p.loss, red[0]);
+}
+
+extern "C" int taco_align_regularity(const float* align, float* dalign, double* loss_sum, int N, int S, int Ti, float overwrought,
+                                     float oneorder_dynamic, float variance_between_row, float alignment_entropy,
+                                     hipStream_t stream) {
+    if (!align || !dalign || !loss_sum || N <= 0 || S <= 0 || Ti <= 0) return TACO_EINVAL;
+    if (overwrought != 0.f && S < 40) return TACO_EINVAL;      // tf.slice(pr, [0,0,40], [N,1,S-41]) needs S >= 40
+    AlignReg p{align, dalign, loss_sum, N, S, Ti, overwrought, oneorder_dynamic, variance_between_row, alignment_entropy};
+    hipLaunchKernelGGL(align_reg_k, dim3(N), dim3(256), 0, stream, p);
+    TACO_RETURN_LAST();
+}
+
 extern "C" int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2,
                             long rows, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
     if (!out || !tgt || !sums2 || ldg < C || (ldg & 3)) return TACO_EINVAL;

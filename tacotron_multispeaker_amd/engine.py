@@ -24,7 +24,7 @@ ACT_NONE, ACT_RELU = 0, 1
 # slots of the attention pointer table (enum TacoAttnPtr in include/taco_hip.h)
 _AP = ['W1C', 'F1', 'W2', 'B2', 'WX', 'WHG', 'WHC', 'BG', 'WQ', 'V', 'KEYS', 'MEM', 'ZEROS', 'P1', 'P2', 'R', 'U', 'C',
        'RH', 'HC', 'Q', 'ALIGN', 'DHC', 'DXP', 'DP2', 'DP1', 'DQ', 'DKEYS', 'DMEM', 'DVPART', 'DA', 'DHT', 'DHPART',
-       'DHCARRY', 'DCTX', 'DCTXCARRY', 'XCHG', 'ERR', 'DE', 'DCTXS']
+       'DHCARRY', 'DCTX', 'DCTXCARRY', 'XCHG', 'ERR', 'DE', 'DCTXS', 'DAEXT']
 AP = {n: i for i, n in enumerate(_AP)}
 
 
@@ -42,6 +42,9 @@ class Engine:
         self.npri = int(3000 / (sample_rate * 0.5) * num_freq)       # tacotron.py:134
         self.init_lr, self.decay_lr, self.beta1, self.beta2 = init_lr, decay_lr, beta1, beta2
         self.tf_sparse_norm = tf_sparse_norm
+        # optional alignment regularisers (tacotron.py:140-171; hparams overwrought / oneorder_dynamic /
+        # variance_between_row / alignment_entropy): weights, all 0.0 = off (set_regularity)
+        self.regularity = dict(overwrought=0.0, oneorder_dynamic=0.0, variance_between_row=0.0, alignment_entropy=0.0)
         f = dict(dtype=torch.float32, device=self.dev)
         self.params = torch.zeros(L.total, **f)
         self.grads = torch.zeros(L.total, **f)
@@ -64,6 +67,7 @@ class Engine:
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
+        self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
         self.world = 1
         self.load_named(named_params if named_params is not None else init_named(L, seed))
 
@@ -355,7 +359,7 @@ class Engine:
     def _chunks(self, N, S, Ti, k=None):
         """Step ranges for the chunk-pipelined decoder (needs the cluster path); [(0, S)] = no pipelining."""
         k = k or self.pipe_chunks
-        if k <= 1 or S < 2 * k or not lib.load().taco_attn_cluster_supported(N, Ti):
+        if k <= 1 or S < 2 * k or self.no_cluster or not lib.load().taco_attn_cluster_supported(N, Ti):
             return [(0, S)]
         # The last chunk is half as long as the others: GRU1/GRU2 of the last chunk run after the attention recurrence has
         # finished (forward), and GRU2/GRU1 of the last chunk run before the attention BPTT can start (backward).
@@ -439,15 +443,25 @@ class Engine:
             'DVPART': b('dVPART', N * Ti, 256), 'DA': b('dA', N * Ti), 'DHT': b('dHT', N, 256),
             'DHPART': b('dHPART', N, 256), 'DHCARRY': b('dHCARRY', N, 256), 'DCTX': b('dCTX', N, 256),
             'DCTXCARRY': b('dCTXCARRY', N, 256),
-            'XCHG': b('xchg_attn', max(self._attn_slots(N, Ti), 8), dtype=torch.int64), 'ERR': self.err,
+            'XCHG': None if self.no_cluster else b('xchg_attn', max(self._attn_slots(N, Ti), 8), dtype=torch.int64), 'ERR': self.err,
             'DE': b('dE', N * S, Ti), 'DCTXS': b('dCTXS', N * S, 256),
+            'DAEXT': b('dALIGN_reg', N * S, Ti) if self.has_regularity else None,
         }
-        arr = (ctypes.c_void_p * len(_AP))(*[t[n].data_ptr() for n in _AP])
+        arr = (ctypes.c_void_p * len(_AP))(*[t[n].data_ptr() if t[n] is not None else None for n in _AP])
         self._attn_dims = (ctypes.c_int * 3)(N, S, Ti)
         self._attn_keep = t
         return arr
 
-    # ---- loss (models/tacotron.py:127-137) -----------------------------------------------------------------------------
+    def set_regularity(self, overwrought=0.0, oneorder_dynamic=0.0, variance_between_row=0.0, alignment_entropy=0.0):
+        """Weights of the optional alignment regularisers (tacotron.py:140-171).  Call before forward()."""
+        self.regularity = dict(overwrought=float(overwrought), oneorder_dynamic=float(oneorder_dynamic),
+                               variance_between_row=float(variance_between_row), alignment_entropy=float(alignment_entropy))
+
+    @property
+    def has_regularity(self):
+        return any(v != 0.0 for v in self.regularity.values())
+
+    # ---- loss (models/tacotron.py:127-171) -----------------------------------------------------------------------------
     def loss(self, linear_targets, with_grad=True):
         N, Ti, To, S = self.dims
         Mp, st = N * To, self.st
@@ -459,14 +473,23 @@ class Engine:
                          1.0 / (Mp * self.nm), 0.0, st)
         lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin,
                          self.loss_sums[2:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
+        self.reg_sum = None
+        if self.has_regularity:
+            # loss_regularity (tacotron.py:140-171): value + gradient wrt the alignments, consumed by the attention BPTT
+            self.reg_sum = self.dslot(2)
+            rg = self.regularity
+            lib.taco_align_regularity(self._bufs['ALIGN'], self.buf('dALIGN_reg', N * S, Ti), self.reg_sum, N, S, Ti, rg['overwrought'],
+                                      rg['oneorder_dynamic'], rg['variance_between_row'], rg['alignment_entropy'], st)
 
     def loss_values(self):
-        """(loss, mel_loss, linear_loss) as Python floats -- synchronises."""
+        """(loss, mel_loss, linear_loss) as Python floats -- synchronises.  loss includes loss_regularity (tacotron.py:171),
+        which is kept in self.loss_regularity."""
         N, Ti, To, S = self.dims
         s = self.loss_sums.cpu().numpy()
         mel = s[0] / (N * To * self.nm)
         lin = 0.5 * s[2] / (N * To * self.nf) + 0.5 * s[3] / (N * To * self.npri)
-        return mel + lin, mel, lin
+        self.loss_regularity = float(self.reg_sum.cpu().numpy()[0]) if self.reg_sum is not None else 0.0
+        return mel + lin + self.loss_regularity, mel, lin
 
     # ---- backward ---------------------------------------------------------------------------------------------------------
     def backward(self):

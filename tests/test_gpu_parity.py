@@ -115,6 +115,52 @@ def test_training_step_matches_oracle(cfg):
         assert np.abs(o['params'][k] - v.detach().numpy()).max() < (1e-4 if eos_only else 1e-5), k
 
 
+@pytest.mark.parametrize('cfg', [(3, 20, 225, 5, 0, False), (2, 12, 135, 3, 2, True), (4, 16, 205, 5, 0, True)])
+def test_alignment_regularisers_match_oracle(cfg, monkeypatch):
+    """loss_regularity of tacotron.py:140-171 (second softmax over the decoder steps, one-order
+    dynamics, first-word mass after step 40, row-sum variance, entropy) and its gradient through the attention BPTT, on
+    the cluster kernels and on the per-step fallback kernels.  Weights are large enough that the regulariser gradient is
+    a visible share of every attention-side gradient.  The one-order term is a sum of |pr[s] - pr[s+1]| whose gradient is a
+    sign: where two neighbouring probabilities agree to fp32 rounding the sign differs from the float64 oracle's, so the
+    gradients are held to 5e-3 here (values and the kink-free terms are exact to 1e-4 / 1e-5)."""
+    from oracle import tacotron_np as onp, tacotron_torch as ot
+    from tacotron_multispeaker_amd.engine import Engine
+    N, Ti, To, r, idn, per_step = cfg
+    if per_step:
+        monkeypatch.setenv('TACO_NO_CLUSTER', '1')
+    reg = dict(overwrought=0.02, oneorder_dynamic=0.01, variance_between_row=0.003, alignment_entropy=5.0)
+    P = onp.init_params(seed=23, r=r, id_num=idn)
+    b = onp.synth_batch(N, Ti, To, r, seed=37, id_num=idn)
+    pad = b['inputs'] == 0
+    b['inputs'][pad] = np.random.RandomState(9).randint(2, 7352, size=int(pad.sum()))     # tie-free max-pool (see above)
+    ts = ot.TrainState(P, torch.float64, id_num=idn, r=r, regularity=reg)
+    last = ts.forward_backward(b)
+    plain = ot.TrainState(P, torch.float64, id_num=idn, r=r).forward_backward(b)
+    eng = Engine(id_num=idn, r=r, named_params=P)
+    eng.set_regularity(**reg)
+    i, l, m, lin, ids = dev_batch(b, eng.dev)
+    eng.forward(i, l, m, ids)
+    eng.loss(lin)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert int(eng.err.item()) == 0
+    loss = eng.loss_values()[0]
+    a_np = last['out']['alignments'].detach().numpy()
+    assert abs(onp.alignment_regularity(a_np, **reg) - last['loss_regularity']) < 1e-9 * abs(last['loss_regularity'])
+    assert abs(eng.loss_regularity - last['loss_regularity']) < 1e-4 * abs(last['loss_regularity'])
+    assert abs(loss - last['loss']) < 1e-5 * last['loss']
+    grads = eng.export_named('grads')
+    gmax = max(float(v.norm()) for v in last['grads'].values())
+    moved = 0
+    for k, v in last['grads'].items():
+        v = v.numpy()
+        err = np.sqrt(((grads[k] - v) ** 2).sum())
+        assert err < 5e-3 * np.sqrt((v ** 2).sum()) + 1e-6 * gmax, k
+        if np.sqrt(((plain['grads'][k].numpy() - v) ** 2).sum()) > 0.05 * np.sqrt((v ** 2).sum()):
+            moved += 1
+    assert moved >= 5          # the regulariser really changes the attention / encoder gradients
+
+
 def test_full_size_c2_forward_matches_cpu_restatement():
     """BASELINE config 2 (N=32, T_in=128, T_out=640, r=5) forward + loss against the fp32 CPU restatement."""
     from oracle import tacotron_np as onp, tacotron_torch as ot

@@ -128,3 +128,37 @@ def test_tf_adam_and_clip():
     g = np.array([0.6, 0.8])                                         # clipped to unit norm
     lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9)
     assert np.allclose(P['w'], np.array([1.0, 2.0]) - lr_t * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8))
+
+
+def test_alignment_regularity_numpy_matches_torch_and_edge_cases():
+    """tacotron.py:140-171 restated twice (numpy value, torch value + autograd); tf.slice edge cases of the
+    `overwrought` term (needs >= 40 decoder steps; S == 40 selects nothing)."""
+    import torch
+    import pytest
+    from oracle import tacotron_np as onp, tacotron_torch as ot
+    rng = np.random.default_rng(3)
+    a = rng.random((3, 9, 50))
+    a /= a.sum(axis=1, keepdims=True)
+    kw = dict(overwrought=0.3, oneorder_dynamic=0.2, variance_between_row=0.1, alignment_entropy=0.5)
+    v_np = onp.alignment_regularity(a, **kw)
+    v_t = float(ot.alignment_regularity(torch.tensor(a), **kw))
+    assert abs(v_np - v_t) < 1e-12 * abs(v_np)
+    assert onp.alignment_regularity(a) == 0.0                                   # all weights 0 (the reference default)
+    # single terms against hand formulas
+    e = np.exp(a - a.max(axis=2, keepdims=True)); pr = e / e.sum(axis=2, keepdims=True)
+    assert abs(onp.alignment_regularity(a, overwrought=1.0) - pr[:, 0, 40:49].sum()) < 1e-12
+    assert abs(onp.alignment_regularity(a, alignment_entropy=2.0) + 2.0 * np.mean(pr * np.log(pr))) < 1e-12
+    a40 = a[:, :, :40]
+    assert onp.alignment_regularity(a40, overwrought=1.0) == 0.0
+    with pytest.raises(ValueError):
+        onp.alignment_regularity(a[:, :, :39], overwrought=1.0)
+    # autograd gradient of the torch restatement against central differences of the numpy one
+    t = torch.tensor(a, requires_grad=True)
+    ot.alignment_regularity(t, **kw).backward()
+    g = t.grad.numpy()
+    for idx in [(0, 0, 41), (1, 3, 0), (2, 8, 49), (0, 0, 10)]:
+        d = 1e-6
+        ap, am = a.copy(), a.copy()
+        ap[idx] += d; am[idx] -= d
+        fd = (onp.alignment_regularity(ap, **kw) - onp.alignment_regularity(am, **kw)) / (2 * d)
+        assert abs(fd - g[idx]) < 1e-5 * max(1.0, abs(fd)), idx
