@@ -66,6 +66,7 @@ class Engine:
         self.stream_c = torch.cuda.Stream(device=self.dev)
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
+        self.last_chunk_frac = float(os.environ.get('TACO_LAST_CHUNK', '0.5'))     # last chunk length / (S / chunks)
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
         self.world = 1
@@ -363,7 +364,7 @@ class Engine:
             return [(0, S)]
         # The last chunk is half as long as the others: GRU1/GRU2 of the last chunk run after the attention recurrence has
         # finished (forward), and GRU2/GRU1 of the last chunk run before the attention BPTT can start (backward).
-        last = max(1, S // (2 * k))
+        last = max(1, int(S * self.last_chunk_frac / k))
         step = (S - last + k - 2) // (k - 1)
         bounds = [min(S - last, i * step) for i in range(k)] + [S]
         return [(bounds[i], bounds[i + 1]) for i in range(k) if bounds[i + 1] > bounds[i]]
