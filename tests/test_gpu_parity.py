@@ -217,7 +217,11 @@ def _conv_ref(x, w, b, T):
 
 
 @pytest.mark.parametrize('M,T,cin,cout,kw', [(96, 12, 128, 128, 3), (4096, 128, 256, 1024, 1), (330, 33, 80, 256, 3),
-                                             (2560, 640, 1024, 256, 3), (77, 77, 256, 1025, 1), (64, 16, 336, 256, 2)])
+                                             (2560, 640, 1024, 256, 3), (77, 77, 256, 1025, 1), (64, 16, 336, 256, 2),
+                                             # ragged everything: K tails of the 16- and 32-deep tiles, N / M tails, T < tile
+                                             (200, 50, 20, 36, 3), (130, 65, 44, 100, 5), (35, 5, 12, 8, 4),
+                                             # shapes that select the 128x128x16 tile configurations (fwd / dX / dW)
+                                             (8192, 8192, 64, 4096, 1), (8192, 8192, 4096, 64, 1), (256, 256, 4096, 2048, 1)])
 def test_conv_gemm_forward_backward(M, T, cin, cout, kw):
     from tacotron_multispeaker_amd._lib import lib, stream
     torch.manual_seed(M + kw)
