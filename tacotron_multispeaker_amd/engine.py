@@ -232,8 +232,11 @@ class Engine:
                                 self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC, N, T, 2, st)
         return OUT
 
-    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx):
-        """dOUT [M,256] gradient wrt the CBHG output; writes the gradient wrt the CBHG input x into dx [M,cin]."""
+    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx, eager=False):
+        """dOUT [M,256] gradient wrt the CBHG output; writes the gradient wrt the CBHG input x into dx [M,cin].
+        eager: release the deferred weight-gradient launches to the side stream after every block (encoder: nothing
+        latency-bound follows that they could disturb, and held back they would run as a serial tail after the main stream)."""
+        flush = self.flush_side if eager else (lambda: None)
         M, C, st = N * T, K * 128, self.st
         b = self._bufs
         OUT, RUC = b[sc + '/out'], b[sc + '/ruc']
@@ -260,6 +263,7 @@ class Engine:
             self.colsum(dZ, self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
             self.gemm_dx(dZ, self.P('%s/highway_%d/kernel' % (sc, i)), other, M, 128, 256, acc=1)
             dhw, other = other, dhw
+            flush()
         if proj[1] != 128:
             dHW0 = self.buf(sc + '/dhw0', M, proj[1])
             self.dense_bwd(b[sc + '/hw0'], dhw, sc + '/highway_dense', M, proj[1], 128, dx=dHW0)
@@ -271,15 +275,18 @@ class Engine:
         self.gemm_dw(b[sc + '/y1'], dC2, self.G(sc + '/proj_2/kernel'), M, proj[0], proj[1], T=T, kw=3)
         dY1 = self.buf(sc + '/dy1', M, proj[0])
         self.gemm_dx(dC2, self.P(sc + '/proj_2/kernel'), dY1, M, proj[0], proj[1], T=T, kw=3)
+        flush()
         dC1 = self.buf(sc + '/dc1', M, proj[0])
         self.bn_bwd(sc + '/proj_1', b[sc + '/c1'], dY1, dC1, M, proj[0], T, 0, 1)
         self.gemm_dw(b[sc + '/pool'], dC1, self.G(sc + '/proj_1/kernel'), M, C, proj[0], T=T, kw=3)
         dPL = self.buf(sc + '/dpool', M, C)
         self.gemm_dx(dC1, self.P(sc + '/proj_1/kernel'), dPL, M, C, proj[0], T=T, kw=3)
+        flush()
         dB = self.buf(sc + '/dbank', M, C)
         self.bn_bwd(sc + '/conv_bank', b[sc + '/bank'], dPL, dB, M, C, T, 1, 1)
         self.gemm_dw(x, dB, self.G(sc + '/conv_bank/kernel'), M, cin, C, T=T, kw=K, bank=K, ldw=128)
         self.gemm_dx(dB, self.P(sc + '/conv_bank/kernel'), dx, M, cin, C, T=T, kw=K, bank=K, ldw=128)
+        flush()
         lib.taco_add(dx, dHW0, dx, M * cin, 0, st)        # residual connection (modules.py:56)
         return dx
 
@@ -580,7 +587,7 @@ class Engine:
         self.gemm_dw(ENC, dKEYS, self.G('attention/memory_layer/kernel'), Me, 256, 256)
         self.gemm_dx(dKEYS, self.P('attention/memory_layer/kernel'), dENC, Me, 256, 256, acc=1)
         dA2 = self.buf('d_enc_p2', Me, 128)
-        self.cbhg_bwd('encoder_cbhg', b['enc_p2'], dENC, N, Ti, 128, 16, (128, 128), self.input_lengths, dA2)
+        self.cbhg_bwd('encoder_cbhg', b['enc_p2'], dENC, N, Ti, 128, 16, (128, 128), self.input_lengths, dA2, eager=True)
         # encoder prenet + embeddings
         lib.taco_relu_bwd(b['enc_p2'], dA2, dA2, Me * 128, st)
         dA1 = self.buf('d_enc_p1', Me, 256)
