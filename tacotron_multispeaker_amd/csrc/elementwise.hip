@@ -375,26 +375,27 @@ __global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, 
 __global__ __launch_bounds__(256) void l1_loss_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt,
                                                 float* __restrict__ grad, int ldg, double* __restrict__ sums, long rows, int C,
                                                 int npri, float w_all, float w_pri) {
-    // rows are strided over workgroups; inside a row consecutive lanes touch consecutive floats (rows of 1025 floats
-    // are not 16-byte aligned, so 4-byte lanes are the coalesced access)
+    // flat (row, column) index over the padded gradient width: consecutive lanes touch consecutive floats (rows of 1025 floats
+    // are not 16-byte aligned, so 4-byte lanes are the coalesced access) and all lanes stay busy for narrow rows (80 mels);
+    // four independent elements per lane and iteration keep enough loads in flight
     float s_all = 0.f, s_pri = 0.f;
-    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
-        const float* o = out + r * ldo;
-        const float* t = tgt + r * ldt;
-        float* g = grad ? grad + r * ldg : nullptr;
-        for (int c = threadIdx.x; c < ldg; c += 256) {
-            float gv = 0.f;
-            if (c < C) {
-                const float d = o[c] - t[c];
-                const float a = fabsf(d);
-                s_all += a;
-                float w = w_all;
-                if (c < npri) { s_pri += a; w += w_pri; }
-                gv = d > 0.f ? w : (d < 0.f ? -w : 0.f);
-            }
-            if (g) g[c] = gv;
+    const unsigned total = (unsigned)(rows * ldg), stride = gridDim.x * 256u;
+    auto one = [&](unsigned e) {
+        const unsigned r = e / (unsigned)ldg, c = e - r * (unsigned)ldg;
+        float gv = 0.f;
+        if ((int)c < C) {
+            const float d = out[(long)r * ldo + c] - tgt[(long)r * ldt + c];
+            const float a = fabsf(d);
+            s_all += a;
+            float w = w_all;
+            if ((int)c < npri) { s_pri += a; w += w_pri; }
+            gv = d > 0.f ? w : (d < 0.f ? -w : 0.f);
         }
-    }
+        if (grad) grad[e] = gv;
+    };
+    unsigned e = blockIdx.x * 256u + threadIdx.x;
+    for (; e + 3u * stride < total && e + 3u * stride >= e; e += 4u * stride) { one(e); one(e + stride); one(e + 2u * stride); one(e + 3u * stride); }
+    for (; e < total; e += stride) one(e);
     // one atomic pair per WORKGROUP (same-address atomics serialise: keep them to ~1k per launch)
     const double a = wave_sum_d((double)s_all), b = wave_sum_d((double)s_pri);
     __shared__ double red[2][4];
@@ -604,7 +605,8 @@ extern "C" int taco_align_regularity(const float* align, float* dalign, double* 
 
 extern "C" int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2,
                             long rows, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
-    if (!out || !tgt || !sums2 || ldg < C || (ldg & 3)) return TACO_EINVAL;
-    hipLaunchKernelGGL(l1_loss_k, dim3((int)(rows < 1024 ? rows : 1024)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
+    if (!out || !tgt || !sums2 || ldg < C || (ldg & 3) || rows * ldg >= (1L << 31)) return TACO_EINVAL;
+    const long blocks = (rows * ldg + 1023) / 1024;
+    hipLaunchKernelGGL(l1_loss_k, dim3((int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
     TACO_RETURN_LAST();
 }

@@ -322,7 +322,13 @@ __global__ __launch_bounds__(256) void conv_gemm_nn2(ConvGemm p) {
     }
     const int pl = (kw - 1) / 2;
     const int ksteps = (p.K + BK - 1) / BK;
-    const int nsteps = kw * ksteps;
+    // blockIdx.z owns a contiguous share of the flattened (tap, k chunk) steps (split-K for few-tile / long-reduction shapes:
+    // partial sums are atomically added into zeroed C, bias + activation are applied by bias_act_k afterwards)
+    const int total = kw * ksteps;
+    const int per = (total + p.splitk - 1) / p.splitk;
+    const int s_begin = blockIdx.z * per;
+    const int nsteps = min(total, s_begin + per) - s_begin;
+    if (nsteps <= 0) return;
 
     // per-lane constants
     int tpos[NVA], acol[NVA];
@@ -355,10 +361,12 @@ __global__ __launch_bounds__(256) void conv_gemm_nn2(ConvGemm p) {
         }
     };
     // next tile to issue: tap i_j, k chunk i_kc; scalar byte offsets soa (A) / sob (B) follow them
-    int i_j = 0, i_kc = 0, soa = 0, sob = 0, issued = 0;
     const int bstep = BK * ldb * 4, btap = p.K * ldb * 4;
+    int i_j = s_begin / ksteps, i_kc = s_begin - i_j * ksteps, issued = 0;
+    int soa = i_kc * BK * 4, sob = __builtin_amdgcn_readfirstlane(i_j * btap + i_kc * bstep);
+    bool need_tap = true;
     auto issue = [&](float* stage) {
-        if (i_kc == 0) tap_offsets(i_j);
+        if (need_tap) { tap_offsets(i_j); need_tap = false; }
         const bool last = KTAIL && i_kc == ksteps - 1;
 #pragma unroll
         for (int v = 0; v < NVA; ++v)
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nn2(ConvGemm p) {
         for (int v = 0; v < NVB; ++v)
             buf_load_lds16(Bb, stage + ASZ + (v * 4 + wave) * RB * BN, last ? vob_last[v] : vob[v], sob);
         ++i_kc; ++issued; soa += BK * 4; sob += bstep;
-        if (i_kc == ksteps) { i_kc = 0; ++i_j; soa = 0; sob = __builtin_amdgcn_readfirstlane(i_j * btap); }
+        if (i_kc == ksteps) { i_kc = 0; ++i_j; soa = 0; sob = __builtin_amdgcn_readfirstlane(i_j * btap); need_tap = true; }
     };
 
     f32x16 acc[BM / 64][BN / 64];
@@ -406,8 +414,32 @@ __global__ __launch_bounds__(256) void conv_gemm_nn2(ConvGemm p) {
             mm.run(smem[1], smem[1] + ASZ, acc);
         }
     }
-    epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane);
+    if (p.splitk == 1) { epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane); return; }
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < BN / 64; ++ni) {
+        const int col = n0 + wn * (BN / 2) + ni * 32 + i;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < BM / 64; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.M) atomicAdd(p.C + rowmap(p, row) * p.ldc + col, acc[mi][ni][r]);
+            }
+    }
 }
+
+// C[m, n] = act(C[m, n] + bias[n]) in place (second pass of a split-K forward GEMM)
+__global__ __launch_bounds__(256) void bias_act_k(ConvGemm p) {
+    const long total = (long)p.M * p.N;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int m = (int)(e / p.N), n = (int)(e - (long)m * p.N);
+        float* c = p.C + rowmap(p, m) * p.ldc + n;
+        *c = apply_act(*c + (p.bias ? p.bias[n] : 0.0f), p.act);
+    }
+}
+
 
 // =====================================================================================================
 // NT: C[m,c] (+)= sum_kw sum_j sum_n dY[m - (j - pl), aoff(kw) + n] * W_kw[j][c][n]      (input gradient)
@@ -973,12 +1005,14 @@ static bool fits31(const ConvGemm& p) {
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-#define NN2_LAUNCH(BM_, BN_, BK_, ST_) do { dim3 g2(cdiv(p.M, BM_), cdiv(p.N, BN_)); \
+#define NN2_LAUNCH(BM_, BN_, BK_, ST_) do { dim3 g2(cdiv(p.M, BM_), cdiv(p.N, BN_), p.splitk); \
         if (p.K % BK_) hipLaunchKernelGGL((conv_gemm_nn2<BM_, BN_, BK_, ST_, true>), g2, dim3(256), 0, stream, p); \
         else hipLaunchKernelGGL((conv_gemm_nn2<BM_, BN_, BK_, ST_, false>), g2, dim3(256), 0, stream, p); } while (0)
 
-static void launch_nn(const ConvGemm& p, hipStream_t stream) {
+static void launch_nn(ConvGemm p, hipStream_t stream) {
     static const int force_v1 = env_int("TACO_NN_V1", 0), force_cfg = env_int("TACO_NN2_TILE", -1);
+    static const int no_split = env_int("TACO_NN_NOSPLIT", 0);
+    p.splitk = 1;
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
     if (force_v1 || !fits31(p)) {
         if (use128(tiles128, p.N)) {
@@ -989,6 +1023,18 @@ static void launch_nn(const ConvGemm& p, hipStream_t stream) {
             hipLaunchKernelGGL((conv_gemm_nn<64, 64, 32>), g, dim3(256), 0, stream, p);
         }
         return;
+    }
+    // few output tiles but a long reduction (encoder proj_1: 128 tiles x 192 steps): split the steps over blockIdx.z
+    {
+        const long tiles = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
+        const int nsteps = p.kw_hi * cdiv(p.K, 32);
+        if (!no_split && !p.bank && !p.accumulate && !p.rb_len && p.M >= 1024 && tiles <= 128 && nsteps >= 64) {
+            int sk = (int)(1024 / tiles);
+            if (sk > nsteps / 16) sk = nsteps / 16;
+            if (sk > 16) sk = 16;
+            if (sk > 1 && hipMemset2DAsync(p.C, (size_t)p.ldc * sizeof(float), 0, (size_t)p.N * sizeof(float), p.M, stream) == hipSuccess)
+                p.splitk = sk;
+        }
     }
     int cfg = force_cfg;
     if (cfg < 0) {
@@ -1002,6 +1048,10 @@ static void launch_nn(const ConvGemm& p, hipStream_t stream) {
     else if (cfg == 2) NN2_LAUNCH(64, 64, 16, 3);
     else if (cfg == 3) NN2_LAUNCH(128, 128, 16, 3);
     else NN2_LAUNCH(64, 64, 32, 3);
+    if (p.splitk > 1 && (p.bias || p.act != ACT_NONE)) {
+        const long work = (long)p.M * p.N;
+        hipLaunchKernelGGL(bias_act_k, dim3((int)((work + 1023) / 1024 > 2048 ? 2048 : (work + 1023) / 1024)), dim3(256), 0, stream, p);
+    }
 }
 
 extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin,

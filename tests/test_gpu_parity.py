@@ -220,6 +220,7 @@ def _conv_ref(x, w, b, T):
                                              (2560, 640, 1024, 256, 3), (77, 77, 256, 1025, 1), (64, 16, 336, 256, 2),
                                              # ragged everything: K tails of the 16- and 32-deep tiles, N / M tails, T < tile
                                              (200, 50, 20, 36, 3), (130, 65, 44, 100, 5), (35, 5, 12, 8, 4),
+                                             (2048, 128, 1024, 128, 3),        # few tiles, long reduction: split-K forward + bias/act pass
                                              # shapes that select the 128x128x16 tile configurations (fwd / dX / dW)
                                              (8192, 8192, 64, 4096, 1), (8192, 8192, 4096, 64, 1), (256, 256, 4096, 2048, 1)])
 def test_conv_gemm_forward_backward(M, T, cin, cout, kw):
