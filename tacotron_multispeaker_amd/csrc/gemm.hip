@@ -1011,7 +1011,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 
 static void launch_nn(ConvGemm p, hipStream_t stream) {
     static const int force_v1 = env_int("TACO_NN_V1", 0), force_cfg = env_int("TACO_NN2_TILE", -1);
-    static const int no_split = env_int("TACO_NN_NOSPLIT", 0);
+    static const int no_split = env_int("TACO_NN_NOSPLIT", 0), split_min_m = env_int("TACO_NN_SPLIT_MINM", 1024);
     p.splitk = 1;
     const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
     if (force_v1 || !fits31(p)) {
@@ -1028,7 +1028,7 @@ static void launch_nn(ConvGemm p, hipStream_t stream) {
     {
         const long tiles = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
         const int nsteps = p.kw_hi * cdiv(p.K, 32);
-        if (!no_split && !p.bank && !p.accumulate && !p.rb_len && p.M >= 1024 && tiles <= 128 && nsteps >= 64) {
+        if (!no_split && !p.bank && !p.accumulate && !p.rb_len && p.M >= split_min_m && tiles <= 128 && nsteps >= 64) {
             int sk = (int)(1024 / tiles);
             if (sk > nsteps / 16) sk = nsteps / 16;
             if (sk > 16) sk = 16;

@@ -32,6 +32,7 @@ def run_engine_step(P, b, r, idn, apply=True):
     eng.loss(lin)
     eng.backward()
     torch.cuda.synchronize()
+    eng.check_errors()                 # a timed-out cluster hand-off would make everything below meaningless
     out = dict(mel=eng.mel_outputs.cpu().numpy(), lin=eng.linear_outputs.cpu().numpy(), align=eng.alignments.cpu().numpy(),
                loss=eng.loss_values(), grads=eng.export_named('grads'))
     if apply:
