@@ -162,8 +162,8 @@ def main():
         step(i)
 
     # HIP-graph replay vs eager launches: keep whichever is faster on this box (the multi-stream graph is not always
-    # the winner once the step is GPU-bound); decided on 3 untimed steps each, identically on every rank
-    if use_graph and world == 1:
+    # the winner once the step is GPU-bound); decided on 3 untimed steps each, identically on every rank (max over ranks)
+    if use_graph:
         def probe(g):
             nonlocal use_graph
             use_graph = g
@@ -173,6 +173,11 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t
         tg, te = probe(True), probe(False)
+        if world > 1:                    # same decision on every rank: compare the slowest rank's times
+            import torch.distributed as dist
+            tt = torch.tensor([tg, te], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tg, te = float(tt[0].item()), float(tt[1].item())
         use_graph = tg <= te
 
     def barrier():
