@@ -342,15 +342,15 @@ class Engine:
                 self.dense_rows(HC, Wp, bp, Y, N, S, s0, s1, 512, 256, 512, 256)
                 self.dense_rows(Y, self.P('decoder_gru_1/wx'), self.P('decoder_gru_1/bias'), gb[1]['XP'], N, S, s0, s1, 256, 768, 256, 768)
                 t = gb[1]['t']
-                lib.taco_gru256_seq_fwd(gb[1]['XP'], self.P('decoder_gru_1/whg'), self.P('decoder_gru_1/whc'), Y, t[0], t[1], t[2],
-                                        t[3], t[4], gb[1]['D'], gb[1]['x'], self.err, N, S, s0, s1, self.st)
+                self.gru256_fwd(gb[1]['XP'], self.P('decoder_gru_1/whg'), self.P('decoder_gru_1/whc'), Y, t, gb[1]['D'], gb[1]['x'],
+                                N, S, s0, s1)
                 ev2 = torch.cuda.Event(); ev2.record(sb)
             sc_.wait_event(ev2)
             with torch.cuda.stream(sc_):
                 self.dense_rows(gb[1]['D'], self.P('decoder_gru_2/wx'), self.P('decoder_gru_2/bias'), gb[2]['XP'], N, S, s0, s1, 256, 768, 256, 768)
                 t = gb[2]['t']
-                lib.taco_gru256_seq_fwd(gb[2]['XP'], self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), gb[1]['D'], t[0], t[1],
-                                        t[2], t[3], t[4], gb[2]['D'], gb[2]['x'], self.err, N, S, s0, s1, self.st)
+                self.gru256_fwd(gb[2]['XP'], self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), gb[1]['D'], t, gb[2]['D'],
+                                gb[2]['x'], N, S, s0, s1)
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
         prev = gb[2]['D']
@@ -378,6 +378,24 @@ class Engine:
 
     def _dims(self, N, S, Ti, s0, s1):
         return (ctypes.c_int * 5)(N, S, Ti, s0, s1)
+
+    # The GRU(256) cluster kernels hold <= 128 batch rows (4 workgroups per 2 rows on 256 CUs); rows are independent, so larger
+    # batches run block by block on contiguous [n0:n1] row slices of the [N,S,*] tensors.
+    GRU256_ROWS = 128
+
+    def gru256_fwd(self, xp, whg, whc, res, t, d, xchg, N, S, s0, s1):
+        for n0 in range(0, N, self.GRU256_ROWS):
+            n1 = min(N, n0 + self.GRU256_ROWS)
+            v = lambda a, w: a.view(N, S * w)[n0:n1]
+            lib.taco_gru256_seq_fwd(v(xp, 768), whg, whc, v(res, 256), v(t[0], 256), v(t[1], 256), v(t[2], 256), v(t[3], 256),
+                                    v(t[4], 256), v(d, 256), xchg, self.err, n1 - n0, S, s0, s1, self.st)
+
+    def gru256_bwd(self, dout, whg, whc, r, u, c, h, dxp, carry, xchg, N, S, s0, s1):
+        for n0 in range(0, N, self.GRU256_ROWS):
+            n1 = min(N, n0 + self.GRU256_ROWS)
+            v = lambda a, w: a.view(N, S * w)[n0:n1]
+            lib.taco_gru256_seq_bwd(v(dout, 256), whg, whc, v(r, 256), v(u, 256), v(c, 256), v(h, 256), v(dxp, 768),
+                                    carry.view(N, 256)[n0:n1], xchg, self.err, n1 - n0, S, s0, s1, self.st)
 
     def dense_rows(self, x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, ldy):
         lib.taco_dense_rows_fwd(x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, cout, ldy, 0, 0, self.st)
@@ -537,15 +555,15 @@ class Engine:
         flush_at = min(len(chunks) - 1, int(os.environ.get('TACO_FLUSH_AT', '99')))
         for ci, (s0, s1) in enumerate(chunks):
             R, U, C, RH, Hh = (b['g2_%s' % k] for k in ('r', 'u', 'c', 'rh', 'h'))
-            lib.taco_gru256_seq_bwd(dD, self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), R, U, C, Hh, dxp[2], car[2],
-                                    xg[2], self.err, N, S, s0, s1, self.st)
+            self.gru256_bwd(dD, self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), R, U, C, Hh, dxp[2], car[2], xg[2],
+                            N, S, s0, s1)
             ev = torch.cuda.Event(); ev.record(cur)
             sb.wait_event(ev)
             with torch.cuda.stream(sb):
                 self.dense_rows_dx(dxp[2], self.P('decoder_gru_2/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dD1 = dD2 + dxp2.Wx2^T
                 R, U, C, RH, Hh = (b['g1_%s' % k] for k in ('r', 'u', 'c', 'rh', 'h'))
-                lib.taco_gru256_seq_bwd(dD, self.P('decoder_gru_1/whg'), self.P('decoder_gru_1/whc'), R, U, C, Hh, dxp[1], car[1],
-                                        xg[1], self.err, N, S, s0, s1, self.st)
+                self.gru256_bwd(dD, self.P('decoder_gru_1/whg'), self.P('decoder_gru_1/whc'), R, U, C, Hh, dxp[1], car[1], xg[1],
+                                N, S, s0, s1)
                 ev2 = torch.cuda.Event(); ev2.record(sb)
             sc_.wait_event(ev2)
             with torch.cuda.stream(sc_):

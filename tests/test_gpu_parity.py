@@ -116,6 +116,41 @@ def test_training_step_matches_oracle(cfg):
         assert np.abs(o['params'][k] - v.detach().numpy()).max() < (1e-4 if eos_only else 1e-5), k
 
 
+@pytest.mark.parametrize('cfg', [(66, 14, 20, 5, 0), (2, 300, 30, 5, 0), (130, 10, 15, 5, 3)])
+def test_shapes_beyond_the_cluster_kernels_fall_back_and_match_oracle(cfg):
+    """Limits of the persistent cluster kernels: the attention clusters hold <= 64 batch rows (8 workgroups per 2 rows on
+    256 CUs) and T_in up to ~270 (key / memory tiles in LDS), the GRU(256) clusters <= 128 rows.  Beyond them the per-step
+    kernels run.  Forward outputs are held to 1e-3 like everywhere else (observed ~1e-6).  Gradients: 1e-3 relative L2 over
+    ALL gradients together, and 2e-2 per tensor (+2e-5 of the largest gradient norm) -- the per-step kernels round
+    differently from the cluster kernels (1e-6 in the forward), which moves a handful of ReLU / max-pool decisions whose
+    operands agree to within rounding across the kink; each such unit shifts one small post-net / encoder gradient tensor
+    by a few 1e-3 of its norm, exactly as in the padded-text configurations above (traced for N=4: ONE flipped unit in
+    post_cbhg/proj_1 = 3.9e-3 of that layer's input gradient, with all kernel inputs equal to 2e-6)."""
+    from oracle import tacotron_np as onp, tacotron_torch as ot
+    from tacotron_multispeaker_amd._lib import lib
+    N, Ti, To, r, idn = cfg
+    assert not lib.load().taco_attn_cluster_supported(N, Ti)
+    P = onp.init_params(seed=29, r=r, id_num=idn)
+    b = onp.synth_batch(N, Ti, To, r, seed=41, id_num=idn)
+    pad = b['inputs'] == 0
+    b['inputs'][pad] = np.random.RandomState(11).randint(2, 7352, size=int(pad.sum()))     # tie-free max-pool
+    ts = ot.TrainState(P, torch.float64, id_num=idn, r=r)
+    last = ts.forward_backward(b)
+    o = run_engine_step(P, b, r, idn, apply=False)
+    assert rel(o['mel'], last['out']['mel_outputs'].detach().numpy()) < TOL
+    assert rel(o['lin'], last['out']['linear_outputs'].detach().numpy()) < TOL
+    assert rel(o['align'], last['out']['alignments'].detach().numpy()) < TOL
+    assert abs(o['loss'][0] - last['loss']) < 1e-5 * last['loss']
+    gmax = max(float(v.norm()) for v in last['grads'].values())
+    e2 = n2 = 0.0
+    for k, v in last['grads'].items():
+        v = v.numpy()
+        err = np.sqrt(((o['grads'][k] - v) ** 2).sum())
+        assert err < 2e-2 * np.sqrt((v ** 2).sum()) + 2e-5 * gmax, k
+        e2 += err ** 2; n2 += (v ** 2).sum()
+    assert np.sqrt(e2 / n2) < TOL
+
+
 @pytest.mark.parametrize('cfg', [(3, 20, 225, 5, 0, False), (2, 12, 135, 3, 2, True), (4, 16, 205, 5, 0, True)])
 def test_alignment_regularisers_match_oracle(cfg, monkeypatch):
     """loss_regularity of tacotron.py:140-171 (second softmax over the decoder steps, one-order
