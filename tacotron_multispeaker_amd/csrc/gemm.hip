@@ -9,8 +9,12 @@
 // inside each length-T sequence (zeros outside) -> no im2col buffer is ever materialised.
 //
 // Math: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains, 256 FLOP/clk/CU = 157 TFLOP/s chip peak).
-// 4 waves per workgroup in a 2x2 arrangement; tiles are staged through LDS with register double
-// buffering (global loads of tile s+1 are in flight while tile s is multiplied).
+// 4 waves per workgroup in a 2x2 arrangement.  Two generations live here:
+//   v1 (conv_gemm_nn/nt/tn): tiles staged global -> VGPR -> LDS with register double buffering; generic 64-bit addressing;
+//      kept as the fallback for operands beyond 2 GiB.
+//   v2 (conv_gemm_nn2/nt2/tn2): tiles staged global -> LDS directly (buffer_load_dwordx4 ... lds), loop-invariant lane
+//      offsets + scalar K walk, statically unrolled ring of LDS stages: no VALU work in the K loop, which on gfx950 is what
+//      limits an fp32 MFMA kernel (profiles/r01_pmc_gemm_v1_v2.md).  The dispatchers below pick v2 whenever it applies.
 #include "common.hpp"
 #include <stdlib.h>
 
