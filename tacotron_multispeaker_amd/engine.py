@@ -644,7 +644,9 @@ class Engine:
         if self.world > 1:
             from . import dp
             if getattr(self, '_buckets', None) is None:
-                self._buckets = dp.bucket_ranges(self.L, 4)
+                # the exchange runs after backward has finished (no overlap yet), so one 35 MB message beats four
+                # smaller ones on the ring; TACO_DP_BUCKETS=4 restores the backward-order buckets
+                self._buckets = dp.bucket_ranges(self.L, int(os.environ.get('TACO_DP_BUCKETS', '1')))
             dp.allreduce_average(self.grads, self.world, self._buckets,
                                  scale_fn=lambda flat, s: lib.taco_scale(flat, flat.numel(), s, self.st))
 
