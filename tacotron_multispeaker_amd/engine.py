@@ -335,7 +335,8 @@ class Engine:
         sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
         Wp, bp = self.P('concat_projection/kernel'), self.P('concat_projection/bias')
         for (s0, s1) in chunks:
-            lib.taco_attn_rnn_fwd(self._attn_ptrs, self._dims(N, S, Ti, s0, s1), self.st)
+            for nb, tab in self._attn_ptrs:
+                lib.taco_attn_rnn_fwd(tab, self._dims(nb, S, Ti, s0, s1), self.st)
             ev = torch.cuda.Event(); ev.record(cur)
             sb.wait_event(ev)
             with torch.cuda.stream(sb):
@@ -367,7 +368,7 @@ class Engine:
     def _chunks(self, N, S, Ti, k=None):
         """Step ranges for the chunk-pipelined decoder (needs the cluster path); [(0, S)] = no pipelining."""
         k = k or self.pipe_chunks
-        if k <= 1 or S < 2 * k or self.no_cluster or not lib.load().taco_attn_cluster_supported(N, Ti):
+        if k <= 1 or S < 2 * k or self.no_cluster or not lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti):
             return [(0, S)]
         # The last chunk is half as long as the others: GRU1/GRU2 of the last chunk run after the attention recurrence has
         # finished (forward), and GRU2/GRU1 of the last chunk run before the attention BPTT can start (backward).
@@ -382,6 +383,7 @@ class Engine:
     # The GRU(256) cluster kernels hold <= 128 batch rows (4 workgroups per 2 rows on 256 CUs); rows are independent, so larger
     # batches run block by block on contiguous [n0:n1] row slices of the [N,S,*] tensors.
     GRU256_ROWS = 128
+    ATTN_ROWS = 64
 
     def gru256_fwd(self, xp, whg, whc, res, t, d, xchg, N, S, s0, s1):
         for n0 in range(0, N, self.GRU256_ROWS):
@@ -473,10 +475,23 @@ class Engine:
             'DE': b('dE', N * S, Ti), 'DCTXS': b('dCTXS', N * S, 256),
             'DAEXT': b('dALIGN_reg', N * S, Ti) if self.has_regularity else None,
         }
-        arr = (ctypes.c_void_p * len(_AP))(*[t[n].data_ptr() if t[n] is not None else None for n in _AP])
-        self._attn_dims = (ctypes.c_int * 3)(N, S, Ti)
+        # floats per batch row of every per-row tensor (weights / scratch shared by all rows: 0)
+        row = dict(F1=S * 256, KEYS=Ti * 256, MEM=Ti * 256, P1=S * 256, P2=S * 128, R=S * 256, U=S * 256, C=S * 256, RH=S * 256,
+                   HC=S * 512, Q=S * 256, ALIGN=S * Ti, DHC=S * 512, DXP=S * 768, DP2=S * 128, DP1=S * 256, DQ=S * 256,
+                   DKEYS=Ti * 256, DMEM=Ti * 256, DVPART=Ti * 256, DA=Ti, DHT=256, DHPART=256, DHCARRY=256, DCTX=256,
+                   DCTXCARRY=256, DE=S * Ti, DCTXS=S * 256, DAEXT=S * Ti)
+        # The attention cluster kernels hold <= 64 batch rows per launch (8 workgroups per 2 rows on 256 CUs); rows are
+        # independent, so a larger batch runs block by block on row-offset pointer tables.  (The per-step fallback kernels
+        # take any N: one table.)
+        blk = self.ATTN_ROWS if (not self.no_cluster and lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti)) else N
+        tables = []
+        for n0 in range(0, N, blk):
+            n1 = min(N, n0 + blk)
+            arr = (ctypes.c_void_p * len(_AP))(*[(t[n].data_ptr() + 4 * n0 * row.get(n, 0)) if t[n] is not None else None
+                                                for n in _AP])
+            tables.append((n1 - n0, arr))
         self._attn_keep = t
-        return arr
+        return tables
 
     def set_regularity(self, overwrought=0.0, oneorder_dynamic=0.0, variance_between_row=0.0, alignment_entropy=0.0):
         """Weights of the optional alignment regularisers (tacotron.py:140-171).  Call before forward()."""
@@ -569,7 +584,8 @@ class Engine:
             with torch.cuda.stream(sc_):
                 self.dense_rows_dx(dxp[1], self.P('decoder_gru_1/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dY = dD1 + dxp1.Wx1^T
                 self.dense_rows_dx(dD, Wp, dHC, N, S, s0, s1, 512, 256, 256, 512, 0)                               # d[h|ctx] = dY.Wp^T
-                lib.taco_attn_rnn_bwd(self._attn_ptrs, self._dims(N, S, Ti, s0, s1), self.st)
+                for nb, tab in self._attn_ptrs:
+                    lib.taco_attn_rnn_bwd(tab, self._dims(nb, S, Ti, s0, s1), self.st)
             if ci == flush_at:
                 # post-net weight gradients fill the CUs the recurrences leave idle; released once the GRU BPTT chunks
                 # (which crowd the first attention chunks) are mostly done
