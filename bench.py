@@ -106,7 +106,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4', 'C5'])
+    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4', 'C5', 'C2x2', 'C2x4'])   # C2xK: K times the C2 batch per GPU
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -121,7 +121,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local if world > 1 else 0)
 
-    cfg = dict(C1=(2, 128, 640, 5, 0), C2=(32, 128, 640, 5, 0), C4=(32, 64, 480, 5, 460), C5=(16, 200, 800, 2, 460))[a.config]
+    cfg = dict(C1=(2, 128, 640, 5, 0), C2=(32, 128, 640, 5, 0), C4=(32, 64, 480, 5, 460), C5=(16, 200, 800, 2, 460),
+               C2x2=(64, 128, 640, 5, 0), C2x4=(128, 128, 640, 5, 0))[a.config]
     N, Ti, To, r, id_num = cfg
     eng = Engine(r=r, id_num=id_num, seed=0, device=dev)       # identical weights on every replica (RandomState(0))
     eng.world = world
