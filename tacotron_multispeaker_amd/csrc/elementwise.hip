@@ -32,22 +32,25 @@ __global__ void embed_gather_k(const int* __restrict__ ids, const int* __restric
 
 // dTable[ids[row]] += dE[row, :Et]; also accumulates sum of squares of the un-deduplicated rows
 // (tf.global_norm over IndexedSlices.values) into sumsq[0].
-__global__ void embed_scatter_text_k(const int* __restrict__ ids, const float* __restrict__ dE, float* __restrict__ dTable,
-                                     double* __restrict__ sumsq, int rows, int Et, int E, int vocab) {
-    const int e4 = Et / 4;
-    const long total = (long)rows * e4;
+__global__ __launch_bounds__(256) void embed_scatter_text_k(const int* __restrict__ ids, const float* __restrict__ dE, float* __restrict__ dTable,
+                                                           double* __restrict__ sumsq, int rows, int Et, int E, int vocab) {
+    // one float per lane: a wave's atomic instruction covers 256 contiguous bytes of one table row (Et % 64 == 0) or of two;
+    // the sum of squares goes through one atomic per WORKGROUP (same-address atomics serialise in L2)
+    const long total = (long)rows * Et;
     float ss = 0.0f;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % e4) * 4;
-        const long row = idx / e4;
-        const float4 g = *reinterpret_cast<const float4*>(dE + row * E + c);
-        int id = min(max(ids[row], 0), vocab - 1);
-        float* d = dTable + (long)id * Et + c;
-        atomicAdd(d + 0, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
-        ss += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / Et;
+        const int c = (int)(idx - row * Et);
+        const float g = dE[row * E + c];
+        const int id = min(max(ids[row], 0), vocab - 1);
+        atomicAdd(dTable + (long)id * Et + c, g);
+        ss = fmaf(g, g, ss);
     }
-    double w = wave_sum_d((double)ss);
-    if ((threadIdx.x & 63) == 0 && sumsq) atomicAdd(sumsq, w);
+    const double w = wave_sum_d((double)ss);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0 && sumsq) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
 }
 
 // dSpk[identities[n]] += sum_t dE[n,t,Et:]; one block per n; sumsq[0] += |sum_t ...|^2
@@ -430,9 +433,9 @@ extern "C" int taco_embed_scatter_bwd(const int* ids, const int* identities, con
                                       double* sparse_sumsq, int N, int Ti, int Et, int Es, int vocab, int id_num,
                                       hipStream_t stream) {
     if (!ids || !dE || !dTable || (Et & 3) || (Es & 3)) return TACO_EINVAL;
-    const long total = (long)N * Ti * (Et / 4);
-    hipLaunchKernelGGL(embed_scatter_text_k, dim3(grid_for(total)), dim3(256), 0, stream, ids, dE, dTable, sparse_sumsq,
-                       N * Ti, Et, Et + Es, vocab);
+    const int blocks = grid_for((long)N * Ti * Et / 4);          // 4 floats per lane and pass; <= 1024 workgroups
+    hipLaunchKernelGGL(embed_scatter_text_k, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, ids, dE, dTable,
+                       sparse_sumsq, N * Ti, Et, Et + Es, vocab);
     if (Es > 0) {
         if (!identities || !dSpk || Es > 256 || 256 % Es) return TACO_EINVAL;
         hipLaunchKernelGGL(embed_scatter_spk_k, dim3(N), dim3(256), 0, stream, identities, dE, dSpk, sparse_sumsq, Ti, Et, Es, id_num);
