@@ -82,7 +82,10 @@ int taco_highway_gate_bwd(const float* HT, const float* x, const float* dy, floa
 int taco_relu_bwd(const float* y, const float* dy, float* dpre, long n, hipStream_t stream);
 int taco_add(const float* a, const float* b, float* y, long n, int accumulate, hipStream_t stream);
 
-/* ---- L1 losses + sign gradients (models/tacotron.py:127-137) ---------------------------------------------------- */
+/* ---- L1 losses + sign gradients (models/tacotron.py:127-137) ----------------------------------------------------
+ * sums2: 2 * TACO_L1_REPL zeroed doubles; replica r holds {sum |d| over all columns, sum |d| over columns < npri} of the
+ * workgroups with index % TACO_L1_REPL == r -- the caller adds the replicas up */
+#define TACO_L1_REPL 8
 int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2, long rows,
                  int C, int npri, float w_all, float w_pri, hipStream_t stream);
 

@@ -372,7 +372,7 @@ __global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, 
 
 // =====================================================================================================
 // L1 losses (models/tacotron.py:127-137) + sign gradients.  out/tgt [rows, C] with leading dims;
-// sums[0] += sum|d| over all columns, sums[1] += sum|d| over columns < npri;
+// sums[2*rep + 0] += sum|d| over all columns, sums[2*rep + 1] += sum|d| over columns < npri  (rep = workgroup % TACO_L1_REPL);
 // grad[row, c] = sign(out - tgt) * (w_all + (c < npri ? w_pri : 0)); padded columns [C, ldg) get 0.
 // =====================================================================================================
 __global__ __launch_bounds__(256) void l1_loss_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt,
@@ -404,9 +404,10 @@ __global__ __launch_bounds__(256) void l1_loss_k(const float* __restrict__ out, 
     __shared__ double red[2][4];
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(sums, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (threadIdx.x == 0) {                       // TACO_L1_REPL replica pairs: ~1k same-address atomics cost ~20 us in L2
+        double* sr = sums + 2 * (blockIdx.x % TACO_L1_REPL);
+        atomicAdd(sr, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(sr + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 

@@ -507,13 +507,13 @@ class Engine:
         N, Ti, To, S = self.dims
         Mp, st = N * To, self.st
         self.linear_targets = linear_targets
-        self.loss_sums = self.dslot(4)
+        self.loss_sums = self.dslot(32)                 # 2 losses x TACO_L1_REPL (8) replica pairs
         dMEL = self.buf('dmel_loss', Mp, self.nm) if with_grad else None
         dLIN = self.buf('dlin', Mp, self.L.ld_lin) if with_grad else None
         lib.taco_l1_loss(self.mel_outputs, self.nm, self.mel_targets, self.nm, dMEL, self.nm, self.loss_sums, Mp, self.nm, 0,
                          1.0 / (Mp * self.nm), 0.0, st)
         lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin,
-                         self.loss_sums[2:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
+                         self.loss_sums[16:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
         self.reg_sum = None
         if self.has_regularity:
             # loss_regularity (tacotron.py:140-171): value + gradient wrt the alignments, consumed by the attention BPTT
@@ -526,9 +526,9 @@ class Engine:
         """(loss, mel_loss, linear_loss) as Python floats -- synchronises.  loss includes loss_regularity (tacotron.py:171),
         which is kept in self.loss_regularity."""
         N, Ti, To, S = self.dims
-        s = self.loss_sums.cpu().numpy()
-        mel = s[0] / (N * To * self.nm)
-        lin = 0.5 * s[2] / (N * To * self.nf) + 0.5 * s[3] / (N * To * self.npri)
+        s = self.loss_sums.cpu().numpy().reshape(2, 8, 2).sum(axis=1)      # [mel | linear] x [all columns, priority columns]
+        mel = s[0, 0] / (N * To * self.nm)
+        lin = 0.5 * s[1, 0] / (N * To * self.nf) + 0.5 * s[1, 1] / (N * To * self.npri)
         self.loss_regularity = float(self.reg_sum.cpu().numpy()[0]) if self.reg_sum is not None else 0.0
         return mel + lin + self.loss_regularity, mel, lin
 
