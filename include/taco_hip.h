@@ -122,6 +122,9 @@ int taco_decoder_infer(const void* const* ptrs, const int* dims, hipStream_t str
 int taco_attn_cluster_supported(int N, int Ti);
 int taco_attn_cluster_xchg_slots(int N, int Ti);
 int taco_attn_cluster_bwd_xchg_slots(int N, int Ti);
+/* which attention-BPTT kernel taco_attn_rnn_bwd runs for (N, Ti): 0 per-step kernels, 1 cluster kernel with the prenet-gradient
+ * weight slices in LDS (T_in <= ~152), 2 cluster kernel with all weight slices in registers (longer inputs) */
+int taco_attn_cluster_bwd_variant(int N, int Ti);
 /* residual decoder GRU(256), whole recurrence in one persistent cluster launch (csrc/gru256.hip); hoisted input
  * projection xp [N,S,768]; d = res + h when d != NULL.  xchg: >= ceil(N/2)*6*256 8-byte granule slots of scratch,
  * err: device int set to 1 if a bounded spin ever times out (results are then invalid).  N <= 128.
@@ -142,10 +145,6 @@ int taco_adam_step(float* params, const float* grads, float* m, float* v, long n
 int taco_bn_ema(float* moving, const float* batch, int n, float momentum, hipStream_t stream);
 int taco_step_inc(int* global_step, hipStream_t stream);
 int taco_scale(float* x, long n, float s, hipStream_t stream);
-
-/* diagnostic: micro-benchmark of the cluster all-gather (scripts/dev_xchg.py); not on the product path */
-int taco_xchg_bench(void* xchg, int* err, float* sink, int nclus, int cw, int len, int iters, int same_xcd, int sleep,
-                    int threads, hipStream_t stream);
 
 /* pointer-table slots of taco_attn_rnn_fwd / taco_attn_rnn_bwd (all fp32 device pointers) */
 enum TacoAttnPtr {

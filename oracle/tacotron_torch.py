@@ -6,8 +6,9 @@ TF-style Adam, BN moving stats).  Two uses only:
     TF-1 cannot run anywhere in this pipeline).
 
 PARITY UNPINNED by the reference (no TF, no reference tests) -- see tacotron_np.py header.
-Built from torch library ops (F.conv1d(padding='same'), F.linear, F.max_pool1d, F.batch_norm)
-rather than the explicit loops of tacotron_np so that the two restatements are independent.
+Built from torch library ops (F.conv1d(padding='same'), F.linear, F.batch_norm; the max-pool is an explicit
+first-max autograd function, cross-checked against F.max_pool1d) rather than the explicit loops of tacotron_np
+so that the two restatements are independent.
 Reference call sites are cited per function.
 """
 import math
@@ -19,6 +20,33 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.99
+DEBUG_TAPS = None          # set to a dict to capture CBHG intermediates (developer diagnostics only)
+
+# ---- piecewise-linear decisions (ReLU on/off, max-pool argmax) ---------------------------------------------------------
+# The training step is piecewise smooth: a ReLU whose pre-activation, or a pooling window whose two operands, agree with the
+# kink to within fp32 rounding can legitimately fall on the other side in an fp32 implementation, and ONE such unit moves a
+# small gradient tensor by a few 1e-3 of its norm.  To compare gradients on the SAME linear piece the oracle can
+#   record  its own decisions and their margins (distance from the kink), and
+#   replay  decisions supplied by the caller (the HIP path's, read back from its saved activations).
+# tests/decisions.py asserts that every replayed decision that differs from the recorded one has a margin within fp32
+# rounding of the kink, i.e. the HIP path never takes a decision the float64 oracle would call clear.
+# DECISIONS = None (default: plain ops) | dict(mode='record'|'replay', masks={site: bool tensor}, margins={site: tensor}).
+# Sites (channel-last shapes): 'prenet/dense_{1,2}' [N,Ti,*]; '<cbhg>/conv_bank/conv1d_k', '<cbhg>/proj_1' [N,T,C];
+# '<cbhg>/pool' [N,T,K*128] (True = first operand wins); '<cbhg>/highway_i/H' [N,T,128]; 'decoder_prenet/dense_{1,2}@s' [N,*].
+DECISIONS = None
+
+
+def relu_site(x, site, channel_first=False):
+    d = DECISIONS
+    if d is None:
+        return F.relu(x)
+    cl = (lambda t: t.transpose(1, 2)) if channel_first else (lambda t: t)
+    if d['mode'] == 'record':
+        d['masks'][site] = cl((x > 0).detach())
+        d['margins'][site] = cl(x.detach().abs())
+        return F.relu(x)
+    return x * cl(d['masks'][site]).to(x.dtype)          # value and gradient follow the supplied on/off decision
+
 
 
 def to_torch(P_np, dtype=torch.float64, requires_grad=True):
@@ -36,7 +64,7 @@ def conv1d_bn(x, P, scope, act, training, stats):
     W = P[scope + '/kernel']                       # [k,Cin,Cout] (TF layout)
     y = F.conv1d(x.transpose(1, 2), W.permute(2, 1, 0), P[scope + '/bias'], padding='same')
     if act == 'relu':
-        y = F.relu(y)
+        y = relu_site(y, scope, channel_first=True)
     if training:
         mu = y.mean(dim=(0, 2))
         var = y.var(dim=(0, 2), unbiased=False)
@@ -48,9 +76,52 @@ def conv1d_bn(x, P, scope, act, training, stats):
     return y.transpose(1, 2)
 
 
-def maxpool2_same(x):
-    """modules.py:45-49: pool 2, stride 1, 'same' (right pad -inf).  Ties route the gradient to the
-    first max (torch max_pool1d == TF CPU MaxPoolGrad first-max-wins)."""
+class _MaxPool2SameFirstMax(torch.autograd.Function):
+    """y[t] = x[t] where first[t] else x[t+1] (first[T-1] is always True): the max-pool of modules.py:45-49 with an explicit
+    argmax; the gradient follows the same routing."""
+
+    @staticmethod
+    def forward(ctx, x, first):
+        nxt = torch.cat([x[:, 1:], x[:, -1:]], dim=1)
+        ctx.save_for_backward(first)
+        return torch.where(first, x, nxt)
+
+    @staticmethod
+    def backward(ctx, g):
+        first, = ctx.saved_tensors
+        g1 = torch.where(first, g, torch.zeros_like(g))
+        g2 = g - g1                                    # gradient of the outputs whose maximum is x[t+1]
+        dx = g1.clone()
+        dx[:, 1:] += g2[:, :-1]
+        return dx, None
+
+
+TIE_REL = {torch.float64: 1e-11, torch.float32: 0.0}      # fp32 (CPU baseline timing only): plain bitwise first max
+
+
+def maxpool2_same(x, site=None):
+    """modules.py:45-49: pool 2, stride 1, 'same' (right pad -inf, so the last frame passes through).  The gradient goes to
+    the FIRST maximum (TF CPU MaxPoolGrad and the HIP kernel).  In float64 two operands closer than 1e-11 of the largest
+    magnitude count as tied: windows that are equal in exact arithmetic (the conv bank over padded text, where every
+    position carries embedding[0]) leave a library conv / batch norm differing in the last bits, and a bitwise argmax would
+    route their gradient by rounding noise.  Equals F.max_pool1d on tie-free inputs (tests/test_oracle.py)."""
+    d = DECISIONS
+    if d is not None and d['mode'] == 'replay' and site is not None:
+        first = d['masks'][site].clone()
+        first[:, -1] = True
+        return _MaxPool2SameFirstMax.apply(x, first)
+    xd = x.detach()
+    nxt = torch.cat([xd[:, 1:], torch.full_like(xd[:, :1], float('-inf'))], dim=1)
+    tol = TIE_REL.get(x.dtype, 0.0) * float(xd.abs().max()) if x.numel() else 0.0
+    first = xd >= nxt - tol
+    if d is not None and site is not None:
+        d['masks'][site] = first
+        d['margins'][site] = (xd - nxt).abs()
+    return _MaxPool2SameFirstMax.apply(x, first)
+
+
+def maxpool2_same_library(x):
+    """library form (F.max_pool1d), kept as the independent cross-check of maxpool2_same on tie-free inputs."""
     xt = F.pad(x.transpose(1, 2), (0, 1), value=float('-inf'))
     return F.max_pool1d(xt, 2, 1).transpose(1, 2)
 
@@ -89,7 +160,7 @@ def bigru(x, lengths, P, scope):
 
 
 def highway(x, P, scope):
-    H = F.relu(F.linear(x, P[scope + '/H/kernel'].t(), P[scope + '/H/bias']))
+    H = relu_site(F.linear(x, P[scope + '/H/kernel'].t(), P[scope + '/H/bias']), scope + '/H')
     T = torch.sigmoid(F.linear(x, P[scope + '/T/kernel'].t(), P[scope + '/T/bias']))
     return H * T + x * (1.0 - T)
 
@@ -98,7 +169,12 @@ def cbhg(x, lengths, P, scope, K, training, stats):
     """modules.py:35-74."""
     bank = torch.cat([conv1d_bn(x, P, '%s/conv_bank/conv1d_%d' % (scope, k), 'relu', training, stats)
                       for k in range(1, K + 1)], dim=-1)
-    pooled = maxpool2_same(bank)
+    pooled = maxpool2_same(bank, scope + '/pool')
+    if DEBUG_TAPS is not None:                       # scripts/dev_tie_debug.py: keep intermediates (and their gradients)
+        for nm, tns in (('bank', bank), ('pooled', pooled)):
+            if tns.requires_grad:
+                tns.retain_grad()
+            DEBUG_TAPS[scope + '/' + nm] = tns
     p1 = conv1d_bn(pooled, P, scope + '/proj_1', 'relu', training, stats)
     p2 = conv1d_bn(p1, P, scope + '/proj_2', None, training, stats)
     hw = p2 + x
@@ -109,9 +185,10 @@ def cbhg(x, lengths, P, scope, K, training, stats):
     return bigru(hw, lengths, P, scope)
 
 
-def prenet(x, P, scope):
-    x = F.relu(F.linear(x, P[scope + '/dense_1/kernel'].t(), P[scope + '/dense_1/bias']))
-    return F.relu(F.linear(x, P[scope + '/dense_2/kernel'].t(), P[scope + '/dense_2/bias']))
+def prenet(x, P, scope, step=None):
+    tag = '' if step is None else '@%d' % step
+    x = relu_site(F.linear(x, P[scope + '/dense_1/kernel'].t(), P[scope + '/dense_1/bias']), scope + '/dense_1' + tag)
+    return relu_site(F.linear(x, P[scope + '/dense_2/kernel'].t(), P[scope + '/dense_2/bias']), scope + '/dense_2' + tag)
 
 
 def decoder_train(enc, mel_targets, P, r, num_mels=80):
@@ -125,7 +202,7 @@ def decoder_train(enc, mel_targets, P, r, num_mels=80):
     outs, aligns = [], []
     for s in range(S):
         frame = torch.zeros(N, num_mels, dtype=enc.dtype) if s == 0 else mel_targets[:, r * s - 1, :]
-        p = prenet(torch.cat([frame, ctx], -1), P, 'decoder_prenet')
+        p = prenet(torch.cat([frame, ctx], -1), P, 'decoder_prenet', step=s)
         h_att = gru_cell(p, h_att, P, 'attention_gru')
         q = h_att @ P['attention/query_layer/kernel']
         score = (torch.tanh(keys + q[:, None, :]) * v).sum(-1)

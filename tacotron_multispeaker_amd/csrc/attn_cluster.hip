@@ -818,6 +818,16 @@ static size_t attn_cluster_bwd_smem(int Ti, bool wlds = false) {
     return f * sizeof(float);
 }
 
+// which BPTT kernel a (N, Ti) launch runs: 0 = shape not held by the cluster path (per-step kernels), 1 = attn_cluster_bwd_k<true>
+// (prenet-gradient weight slices parked in LDS; fits while Ti <= ~152), 2 = attn_cluster_bwd_k<false> (all weights in registers; the
+// key / memory tiles of long inputs need the LDS).  TACO_ATTN_NO_WLDS=1 forces variant 2 (tests).
+extern "C" int taco_attn_cluster_bwd_variant(int N, int Ti) {
+    if (!taco_attn_cluster_supported(N, Ti)) return 0;
+    const char* e = getenv("TACO_ATTN_NO_WLDS");
+    const bool no_wlds = e && e[0] && e[0] != '0';
+    return (!no_wlds && attn_cluster_bwd_smem(Ti, true) <= 160 * 1024) ? 1 : 2;
+}
+
 extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
     return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128);
 }
@@ -832,8 +842,7 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
     }
     if (attn_cluster_bwd_smem(p.Ti, false) > 160 * 1024) return TACO_EINVAL;
     if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
-    static const bool no_wlds = getenv("TACO_ATTN_NO_WLDS") != nullptr;
-    if (!no_wlds && attn_cluster_bwd_smem(p.Ti, true) <= 160 * 1024)
+    if (taco_attn_cluster_bwd_variant(p.N, p.Ti) == 1)
         hipLaunchKernelGGL(attn_cluster_bwd_k<true>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, true), st, p);
     else
         hipLaunchKernelGGL(attn_cluster_bwd_k<false>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, false), st, p);

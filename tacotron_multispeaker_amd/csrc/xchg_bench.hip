@@ -1,10 +1,11 @@
 // Diagnostic micro-benchmark of the cluster all-gather used by the persistent recurrence kernels: CW workgroups
 // per cluster publish LEN granules each and gather everyone else's, ITERS times (one __syncthreads per round).
-// Reported by scripts/dev_xchg.py as microseconds per exchange round; not on the product path.
+// Reported by scripts/dev_xchg.py as microseconds per exchange round; not on the product path (csrc/dev_tools.h).
 #include "common.hpp"
-typedef unsigned long long u64;
+#include "dev_tools.h"
+#include "xcd_granule.hpp"
 
-struct XB { u64* x; int* err; int cw, len, iters, same_xcd, sleep, threads; float* sink; };
+struct XB { u64* x; int* err; int cw, len, iters, same_xcd, sleep, threads, mode; float* sink; };
 
 __global__ __launch_bounds__(512) void xchg_bench_k(XB p) {
     const int tid = threadIdx.x;
@@ -12,16 +13,25 @@ __global__ __launch_bounds__(512) void xchg_bench_k(XB p) {
     int w, cl;
     if (p.same_xcd && (nclus & 7) == 0) { const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3; w = q % p.cw; cl = (q / p.cw) * 8 + xcd; }
     else { w = blockIdx.x % p.cw; cl = blockIdx.x / p.cw; }
-    u64* X0 = p.x + (long)cl * 2 * p.cw * p.len;      // two alternating regions (a round may only overwrite data
-                                                      // that every peer has provably consumed)
+    u64* X0 = p.x + (long)cl * (2 * p.cw * p.len + 16) + 16;      // 16 placement slots, then two alternating regions
     __shared__ float lds[4096];
+    __shared__ int local_s;
+    // mode 1: the L2-local granule form is legal only if the whole cluster sits on one XCD -- verified, never assumed
+    bool local = false;
+    if (p.mode == 1) {
+        if (tid == 0) local_s = cluster_on_one_xcd(p.x + (long)cl * (2 * p.cw * p.len + 16), w, p.cw, p.err) ? 1 : 0;
+        __syncthreads();
+        local = local_s != 0;
+        if (!local && tid == 0) atomicExch(p.err, 2);
+    }
     float acc = 0.f;
     for (int it = 0; it < p.iters; ++it) {
         const unsigned epoch = it + 1;
         u64* X = X0 + (it & 1) * p.cw * p.len;
         if (tid < p.len) {
             const float v = (float)(it + tid + w);
-            __hip_atomic_store(X + w * p.len + tid, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (local) put_granule_xcd(X + w * p.len + tid, epoch, v);
+            else put_granule(X + w * p.len + tid, epoch, v);
         }
         const int tot = (p.cw - 1) * p.len;
         for (int g = tid; g < tot; g += blockDim.x) {
@@ -35,7 +45,9 @@ __global__ __launch_bounds__(512) void xchg_bench_k(XB p) {
                 if (p.sleep) __builtin_amdgcn_s_sleep(1);
                 x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lds[g & 4095] = __uint_as_float((unsigned)x);
+            const float got = __uint_as_float((unsigned)x);
+            if (got != (float)(it + jj + pw)) atomicExch(p.err, 3);       // every word is checked
+            lds[g & 4095] = got;
         }
         __syncthreads();
         acc += lds[tid & 4095];
@@ -44,11 +56,11 @@ __global__ __launch_bounds__(512) void xchg_bench_k(XB p) {
     if (acc == 123.456f) p.sink[0] = acc;
 }
 
-extern "C" int taco_xchg_bench(void* xchg, int* err, float* sink, int nclus, int cw, int len, int iters, int same_xcd, int sleep,
-                               int threads, hipStream_t st) {
+extern "C" int taco_dev_xchg_bench(void* xchg, int* err, float* sink, int nclus, int cw, int len, int iters, int same_xcd,
+                                   int sleep, int threads, int mode, hipStream_t st) {
     if (!xchg || !err || !sink || nclus * cw > 256 || len > 512 || threads > 512) return TACO_EINVAL;
-    if (hipMemsetAsync(xchg, 0, (size_t)nclus * 2 * cw * len * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
-    XB p{(u64*)xchg, err, cw, len, iters, same_xcd, sleep, threads, sink};
+    if (hipMemsetAsync(xchg, 0, (size_t)nclus * (2 * cw * len + 16) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    XB p{(u64*)xchg, err, cw, len, iters, same_xcd, sleep, threads, mode, sink};
     hipLaunchKernelGGL(xchg_bench_k, dim3(nclus * cw), dim3(threads), 0, st, p);
     TACO_RETURN_LAST();
 }

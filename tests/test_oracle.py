@@ -80,6 +80,23 @@ def test_maxpool_last_frame_passthrough():
     assert np.array_equal(onp.maxpool2_same(x)[0, :, 0], [5, 5, 7, 7])
 
 
+def test_maxpool_first_max_routing_and_library_cross_check():
+    """oracle max-pool: value and gradient equal F.max_pool1d on tie-free inputs; exact ties and ties within rounding
+    noise (equal in exact arithmetic) send the gradient to the FIRST maximum like TF CPU MaxPoolGrad / the HIP kernel."""
+    torch.manual_seed(3)
+    x = torch.randn(3, 17, 5, dtype=torch.float64, requires_grad=True)
+    g = torch.randn(3, 17, 5, dtype=torch.float64)
+    ya = ot.maxpool2_same(x); ga, = torch.autograd.grad(ya, x, g)
+    yb = ot.maxpool2_same_library(x); gb, = torch.autograd.grad(yb, x, g)
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    t = torch.tensor([[[1.0], [1.0], [1.0 + 1e-14], [1.0], [0.5]]], dtype=torch.float64, requires_grad=True)
+    y = ot.maxpool2_same(t)
+    d, = torch.autograd.grad(y, t, torch.tensor([[[1.0], [10.0], [100.0], [1000.0], [10000.0]]], dtype=torch.float64))
+    # windows (0,1) tie -> 0; (1,2) near-tie -> 1; (2,3) near-tie -> 2; (3,4) -> 3; last frame passes through
+    assert d[0, :, 0].tolist() == [1.0, 10.0, 100.0, 1000.0, 10000.0]
+    assert y[0, 2, 0] == 1.0 + 1e-14                      # the VALUE is still the true maximum
+
+
 def test_batch_norm_of_constant_channel_is_beta():
     x = np.ones((2, 5, 3)) * np.array([1.0, -2.0, 0.5])
     y, mu, var = onp.batch_norm_train(x, np.array([2.0, 3.0, 4.0]), np.array([0.1, 0.2, 0.3]))

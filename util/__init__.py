@@ -1,24 +1,28 @@
-class ValueWindow():
-    """Moving window of the last `window_size` values (reference util/__init__.py:1-22)."""
+"""Small training-loop helpers with the interface train.py expects from the reference's util package
+(ValueWindow: util/__init__.py:1-22 there)."""
+from collections import deque
+
+
+class ValueWindow(object):
+    """Running statistics over the most recent `window_size` appended values."""
 
     def __init__(self, window_size=100):
-        self._window_size = window_size
-        self._values = []
+        self._values = deque(maxlen=int(window_size))
 
     def append(self, x):
-        self._values = self._values[-(self._window_size - 1):] + [x]
+        self._values.append(x)
 
-    @property
-    def sum(self):
-        return sum(self._values)
+    def reset(self):
+        self._values.clear()
 
     @property
     def count(self):
         return len(self._values)
 
     @property
-    def average(self):
-        return self.sum / max(1, self.count)
+    def sum(self):
+        return float(sum(self._values)) if self._values else 0
 
-    def reset(self):
-        self._values = []
+    @property
+    def average(self):
+        return self.sum / self.count if self._values else 0.0

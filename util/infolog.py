@@ -1,28 +1,43 @@
-"""print + append-to-file logger (reference util/infolog.py:8-20)."""
-from datetime import datetime
+"""Console + run-log writer with the interface of the reference's util/infolog.py:8-20 (`init(path)`, `log(msg)`):
+every message is echoed to stdout and, once init() was called, appended to the log file with a millisecond
+timestamp.  Each init() starts a new banner-separated section in the (appended) file."""
+import atexit
+import datetime
+import threading
 
-_format = '%Y-%m-%d %H:%M:%S.%f'
-_file = None
+_BANNER = '-' * 65
+_lock = threading.Lock()
+_sink = None
+
+
+def _stamp():
+    now = datetime.datetime.now()
+    return '%s.%03d' % (now.strftime('%Y-%m-%d %H:%M:%S'), now.microsecond // 1000)
+
+
+def _close_logfile():
+    global _sink
+    with _lock:
+        if _sink is not None:
+            _sink.close()
+        _sink = None
 
 
 def init(filename):
-    global _file
+    global _sink
     _close_logfile()
-    _file = open(filename, 'a')
-    _file.write('\n-----------------------------------------------------------------\n')
-    _file.write('Starting new training run\n')
-    _file.write('-----------------------------------------------------------------\n')
+    with _lock:
+        _sink = open(filename, 'a', encoding='utf-8')
+        _sink.write('\n%s\nStarting new training run\n%s\n' % (_BANNER, _BANNER))
+        _sink.flush()
 
 
 def log(msg):
     print(msg, flush=True)
-    if _file is not None:
-        _file.write('[%s]  %s\n' % (datetime.now().strftime(_format)[:-3], msg))
-        _file.flush()
+    with _lock:
+        if _sink is not None:
+            _sink.write('[%s]  %s\n' % (_stamp(), msg))
+            _sink.flush()
 
 
-def _close_logfile():
-    global _file
-    if _file is not None:
-        _file.close()
-        _file = None
+atexit.register(_close_logfile)
