@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark: mel-frames/sec of the Tacotron multispeaker TRAINING STEP (forward + backward +
-gradient all-reduce + clipped Adam) on N MI355X GPUs of one node, BASELINE.json config "LJSpeech
-single-speaker, batch_size=32, r=5" (C2: N=32, T_in=128, T_out=640), synthetic LJSpeech-shaped batches,
+"""Headline benchmark: mel-frames/sec of the Tacotron multispeaker TRAINING STEP (forward + backward + gradient
+all-reduce overlapped with backward + clipped Adam) on N MI355X GPUs of one node, BASELINE.json config "LJSpeech
+single-speaker, batch_size=32, r=5" (C2: N=32, T_in=128, T_out=640), synthetic LJSpeech-shaped batches (SURVEY.md 8(d)),
 random-init weights (TF initialisers), fp32 arithmetic like the reference.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  Extra objects on that line:
-  roofline      -- the dominant MFMA kernel (post-net proj_1 conv as fp32 implicit GEMM), timed live with HIP
-                   events on the launch stream: algorithmic FLOPs per launch / average duration vs the fp32
-                   MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
-  step_roofline -- the whole step against the same peak: 349.5 GFLOP / ms_per_step
-  cpu_baseline  -- the CPU stand-in (oracle/tacotron_torch.py, fp32, same step) timed on this box's host cores
-                   (rank 0, N=1 only); TF-1 itself cannot run anywhere in this pipeline (SURVEY.md 8(c,d)).
+Prints ONE JSON line (rank 0).  Besides the contract fields:
+  ms_per_step_median   median of the K per-step times (HIP events on the main stream); ms_per_step = total / K
+  roofline             the kernel family with the largest IN-STEP time (HIP events around every launch of the family on the
+                       stream it is launched on, during extra eager steps of the same workload): algorithmic FLOPs per launch /
+                       average launch duration vs the fp32-MFMA peak (157.3 TFLOP/s); traffic = HBM bytes per launch from the
+                       committed rocprofv3 --pmc passes (profiles/, path in the object) or null
+  kernel_families      the same figures for every timed family (the recurrences are latency-bound: their fraction of the
+                       MFMA peak is reported as what it is)
+  gemm_roofline        the largest single MFMA launch (post-net proj_1 conv) timed back to back in isolation
+  step_roofline        the whole step: 349.5 GFLOP / ms_per_step vs the same peak, and 1.56 GB vs 8 TB/s
+  parity               max relative error / mean |diff| of mel and linear outputs vs the fp32 CPU restatement on the bench batch
+  cpu_baseline         the CPU stand-in (oracle/tacotron_torch.py, fp32, same step) on this box's host cores (rank 0, N=1 only);
+                       TF-1 itself cannot run anywhere in this pipeline (SURVEY.md 8(c,d))
+  allreduce_exposed_ms (N > 1) time the optimizer's stream waits for the gradient exchange after backward has finished
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,6 +41,7 @@ from tacotron_multispeaker_amd import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')    # {family: {"bytes_per_launch": ..., "source": ...}}
 
 
 def step_flops(N, Ti, To, r, E_in=256):
@@ -47,8 +56,14 @@ def step_flops(N, Ti, To, r, E_in=256):
     return float(f)
 
 
-def time_dominant_kernel(eng, N, To, iters=20):
-    """post_cbhg proj_1: conv1d k=3, 1024 -> 256 over [N*To] rows = the largest single MFMA launch."""
+def step_bytes(N, Ti, To, r, n_params):
+    """Algorithmic HBM bytes per step: targets + outputs once, 40 B/param, saved activations written + read."""
+    S = To // r
+    return 2.0 * 4 * N * To * (80 + 1025) + 40.0 * n_params + 2.0 * 4 * (5632 * N * Ti + 5088 * N * S + 4128 * N * To)
+
+
+def time_isolated_gemm(eng, N, To, iters=20):
+    """post_cbhg proj_1: conv1d k=3, 1024 -> 256 over [N*To] rows = the largest single MFMA launch, back to back."""
     from tacotron_multispeaker_amd._lib import lib
     M = N * To
     X = eng._bufs['post_cbhg/pool']
@@ -65,48 +80,101 @@ def time_dominant_kernel(eng, N, To, iters=20):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * 3 * 1024 * 256
-    # traffic: HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counter values;
-    # profiles/r01_pmc_gemm_v1_v2.md) -- measured offline on the same kernel and shape, not in this run
-    return dict(kernel='conv_gemm_nn2<64,64,32,3> (post_cbhg/proj_1 conv1d k=3 1024->256, M=%d)' % M,
-                bound='mfma', achieved=flops / (ms * 1e-3) / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                frac=flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=181.2e6 if M == 20480 else None,
-                traffic_unit='bytes/launch (160.7 MB FETCH_SIZE + 20.5 MB WRITE_SIZE; algorithmic 108 MB)',
+    tf = flops / (ms * 1e-3) / 1e12
+    return dict(kernel='conv_gemm_nn2<64,64,32,3> (post_cbhg/proj_1 conv1d k=3 1024->256, M=%d), isolated back-to-back launches' % M,
+                bound='mfma', achieved=tf, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=tf / PEAK_FP32_MFMA_TFLOPS,
                 avg_launch_us=ms * 1e3, flops_per_launch=flops)
 
 
-def cpu_baseline(N, Ti, To, r, steps=2):
+def kernel_families(eng, run_step, steps=5):
+    """In-step duration of every timed kernel family: HIP events around each launch on its own stream (Engine._timed)."""
+    eng.ktime = []
+    for i in range(steps):
+        run_step(i)
+    torch.cuda.synchronize()
+    fam = {}
+    for name, flops, e0, e1 in eng.ktime:
+        f = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        f['launches'] += 1; f['ms'] += e0.elapsed_time(e1); f['flops'] += flops
+    eng.ktime = None
+    traffic = {}
+    if os.path.exists(os.path.join(ROOT, TRAFFIC_FILE)):
+        traffic = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+    out = []
+    for name, f in fam.items():
+        tf = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
+        latency = 'recurrence' in name or 'GRU' in name
+        tr = traffic.get(name, {})
+        out.append(dict(kernel=name, bound='latency (serial recurrence; charged against the MFMA peak)' if latency else 'mfma',
+                        launches_per_step=f['launches'] / steps, ms_per_step=f['ms'] / steps,
+                        avg_launch_us=f['ms'] / f['launches'] * 1e3, flops_per_launch=f['flops'] / f['launches'],
+                        achieved=tf, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=tf / PEAK_FP32_MFMA_TFLOPS,
+                        traffic=tr.get('bytes_per_launch'), traffic_source=tr.get('source')))
+    out.sort(key=lambda d: -d['ms_per_step'])
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(P, N, Ti, To, r, id_num, steps=3):
     """CPU stand-in of the same training step (oracle/tacotron_torch.py, fp32) on this box's host cores."""
     import warnings
     warnings.filterwarnings('ignore')
     from oracle import tacotron_np as onp, tacotron_torch as ot
-    cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
-        pass
-    cores = min(cores, 16)                 # the GPU box's CPU share per GPU; more threads only add contention
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    P = onp.init_params(seed=0, r=r)
-    ts = ot.TrainState(P, torch.float32, r=r)
-    ts.step(onp.synth_batch(2, 32, 40, r, seed=1))         # warm-up (tiny)
-    b = onp.synth_batch(N, Ti, To, r, seed=1234)
+    ts = ot.TrainState(P, torch.float32, id_num=id_num, r=r)
+    ts.step(onp.synth_batch(2, 32, 40, r, seed=1, id_num=id_num))         # warm-up (tiny)
+    b = onp.synth_batch(N, Ti, To, r, seed=1234, id_num=id_num)
+    ts.step(b)                                                            # warm-up (full size)
     t = time.time()
     for _ in range(steps):
         ts.step(b)
     dt = (time.time() - t) / steps
-    return dict(value=N * To / dt, unit='mel-frames/sec', cores=cores, kind='port', sec_per_step=dt,
-                sample='%d full training steps of the C2 batch (N=%d,T_in=%d,T_out=%d,r=%d), fp32 PyTorch-CPU restatement '
-                       '(oracle/tacotron_torch.py); TF-1 unavailable' % (steps, N, Ti, To, r))
+    return dict(value=N * To / dt, unit='mel-frames/sec', cores=cores, cpu=cpu_model(), kind='port', sec_per_step=dt,
+                sample='%d full training steps (after 1 warm-up) of the bench batch (N=%d,T_in=%d,T_out=%d,r=%d), fp32 PyTorch-CPU '
+                       'restatement (oracle/tacotron_torch.py) on %d threads; TF-1 unavailable' % (steps, N, Ti, To, r, cores))
+
+
+def parity_vs_oracle(eng, P, batch, r, id_num):
+    """mel / linear outputs of the HIP forward vs the fp32 CPU restatement on the same weights and batch."""
+    from oracle import tacotron_torch as ot
+    Pt = ot.to_torch(P, torch.float32, requires_grad=False)
+    with torch.no_grad():
+        ref = ot.forward(Pt, batch['inputs'], batch['input_lengths'], torch.tensor(batch['mel_targets']), batch['identities'],
+                         id_num, r)
+    dev_b = synth.batch_to_device(batch, eng.dev)
+    eng.forward(dev_b[0], dev_b[1], dev_b[2], dev_b[4])
+    torch.cuda.synchronize()
+    out = {}
+    for k, mine in (('mel', eng.mel_outputs), ('linear', eng.linear_outputs)):
+        a, c = mine.cpu().numpy().astype(np.float64), ref[k + '_outputs'].numpy().astype(np.float64)
+        out[k + '_max_rel'] = float(np.abs(a - c).max() / np.abs(c).max())
+        out[k + '_l1'] = float(np.abs(a - c).mean())
+    out['reference'] = 'oracle/tacotron_torch.py fp32 forward (the stand-in for the TF reference, parity unpinned: DESIGN.md section 2)'
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4', 'C5', 'C2x2', 'C2x4'])   # C2xK: K times the C2 batch per GPU
+    ap.add_argument('--no-families', action='store_true', help='skip the extra instrumented steps (rocprofv3 runs)')
+    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C2x', 'C4', 'C5', 'C2x2', 'C2x4'])   # C2xK: K times the C2 batch per GPU
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -121,10 +189,12 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local if world > 1 else 0)
 
-    cfg = dict(C1=(2, 128, 640, 5, 0), C2=(32, 128, 640, 5, 0), C4=(32, 64, 480, 5, 460), C5=(16, 200, 800, 2, 460),
-               C2x2=(64, 128, 640, 5, 0), C2x4=(128, 128, 640, 5, 0))[a.config]
+    cfg = dict(C1=(2, 128, 640, 5, 0), C2=(32, 128, 640, 5, 0), C2x=(32, 192, 810, 5, 0), C4=(32, 64, 480, 5, 460),
+               C5=(16, 200, 800, 2, 460), C2x2=(64, 128, 640, 5, 0), C2x4=(128, 128, 640, 5, 0))[a.config]
     N, Ti, To, r, id_num = cfg
-    eng = Engine(r=r, id_num=id_num, seed=0, device=dev)       # identical weights on every replica (RandomState(0))
+    from tacotron_multispeaker_amd.params import init_named, ParamLayout
+    P = init_named(ParamLayout(id_num=id_num, r=r), 0)          # identical weights on every replica (RandomState(0))
+    eng = Engine(r=r, id_num=id_num, named_params=P, device=dev)
     eng.world = world
     pool = [synth.batch_to_device(synth.synth_batch(N, Ti, To, r, seed=1234 + rank * 1000 + i, id_num=id_num), dev) for i in range(4)]
     static = [t.clone() if t is not None else None for t in pool[0]]
@@ -139,10 +209,15 @@ def main():
         eng.loss(static[3])
         eng.backward()
 
-    # eager warm-up allocates the workspace; then capture the step into HIP graphs
-    fwd_bwd(); eng.allreduce_grads(); eng.optimizer_step()
+    def eager_step(i):
+        load(i)
+        fwd_bwd(); eng.allreduce_grads(); eng.optimizer_step()
+
+    # eager warm-up allocates the workspace; then (single GPU) capture the step into HIP graphs.  With more than one rank the
+    # step stays eager: the bucket all-reduces are launched from inside backward on the communication stream.
+    eager_step(0)
     torch.cuda.synchronize()
-    use_graph = not a.no_graph
+    use_graph = (not a.no_graph) and world == 1
     if use_graph:
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
@@ -151,19 +226,18 @@ def main():
             eng.optimizer_step()
 
     def step(i):
-        load(i)
         if use_graph:
+            load(i)
             g1.replay()
-            eng.allreduce_grads()       # RCCL all-reduce of the flat fp32 gradient (no-op at world 1)
             g2.replay()
         else:
-            fwd_bwd(); eng.allreduce_grads(); eng.optimizer_step()
+            eager_step(i)
 
     for i in range(a.warmup):
         step(i)
 
-    # HIP-graph replay vs eager launches: keep whichever is faster on this box (the multi-stream graph is not always
-    # the winner once the step is GPU-bound); decided on 3 untimed steps each, identically on every rank (max over ranks)
+    # HIP-graph replay vs eager launches: keep whichever is faster on this box (the multi-stream graph is not always the
+    # winner once the step is GPU-bound); decided on 3 untimed steps each
     if use_graph:
         def probe(g):
             nonlocal use_graph
@@ -174,21 +248,21 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t
         tg, te = probe(True), probe(False)
-        if world > 1:                    # same decision on every rank: compare the slowest rank's times
-            import torch.distributed as dist
-            tt = torch.tensor([tg, te], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tg, te = float(tt[0].item()), float(tt[1].item())
         use_graph = tg <= te
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
+    if world > 1:
+        eng.exposed_events = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         step(a.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -196,27 +270,50 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     loss = eng.loss_values()[0]
+    err = int(eng.err.item())
+    exposed = None
+    if world > 1:
+        exposed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in eng.exposed_events[-a.steps:]]))
+        eng.exposed_events = None
 
     if rank == 0:
         ms = dt / a.steps * 1e3
         frames = world * N * To
         fl = 3.0 * step_flops(N, Ti, To, r, 256 + (64 if id_num > 1 else 0))
+        by = step_bytes(N, Ti, To, r, eng.L.total)
         out = {
             'metric': 'mel-frames/sec/node (batch32, r=5) training step', 'value': frames / (dt / a.steps),
             'unit': 'mel-frames/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms,
+            'ms_per_step_median': statistics.median(per_step),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: LJSpeech-shaped batch_size=%d/GPU, T_in=%d, T_out=%d, outputs_per_step=%d, id_num=%d, '
                                    'full training step (fwd+bwd+allreduce+clipped Adam)' % (a.config, N, Ti, To, r, id_num),
                        'global_batch': N * world, 'parallelism': 'dp%d' % world, 'hip_graph': use_graph},
-            'loss_after': loss,
+            'loss_after': loss, 'cluster_handoff_timeouts': err,
             'step_roofline': {'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS,
                               'unit': 'TFLOP/s', 'frac': fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                              'flops_per_step': fl},
+                              'flops_per_step': fl, 'hbm': {'achieved': by / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
+                                                            'unit': 'GB/s', 'frac': by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                            'algorithmic_bytes_per_step': by}},
         }
-        out['roofline'] = time_dominant_kernel(eng, N, To) if a.config in ('C2',) else None
+        if exposed is not None:
+            out['allreduce_exposed_ms'] = exposed
+        if err:
+            out['error'] = 'a persistent cluster kernel reported a hand-off timeout: the timed steps are INVALID'
+        if not a.no_families:
+            fams = kernel_families(eng, eager_step)
+            out['roofline'] = dict(fams[0], timing='HIP events around every launch of the family on its stream, 5 eager steps of the '
+                                                   'same workload after the timed region')
+            out['kernel_families'] = fams[1:]
+        else:
+            out['roofline'] = None
+        out['gemm_roofline'] = time_isolated_gemm(eng, N, To) if a.config in ('C2',) else None
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N, Ti, To, r)
+            batch = synth.synth_batch(N, Ti, To, r, seed=1234, id_num=id_num)
+            out['parity'] = parity_vs_oracle(eng, eng.export_named('params'), batch, r, id_num)     # the weights after the timed steps
+            out['cpu_baseline'] = cpu_baseline(P, N, Ti, To, r, id_num)
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         else:
             out['cpu_baseline'] = None

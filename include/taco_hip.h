@@ -116,7 +116,10 @@ int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int
 int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 /* free-running inference decoder (reference models/helpers.py:7-38 TacoTestHelper, models/tacotron.py:86-94):
- * ptrs indexed by enum TacoInferPtr (all required), dims = {N, S = steps to run, Ti, r, num_mels} */
+ * ptrs indexed by enum TacoInferPtr (all required), dims = {N, S = max_iters (row stride of the [N,S,*] outputs), Ti, r,
+ * num_mels, s0, s1}: enqueues decoder steps [s0, s1); state carries over between calls through HC / OUT / H1 / H2.
+ * TACO_IP_STOP implements the reference's stop token: the caller sets stop[0] = S and stop[1..N] = 0 before step 0; after the
+ * first step at which every row has produced an all-zero r-frame output (sticky per row) stop[0] = that step + 1. */
 int taco_decoder_infer(const void* const* ptrs, const int* dims, hipStream_t stream);
 /* persistent-cluster path of the attention recurrence: shape support (1/0) and granule scratch size in 8-byte slots */
 int taco_attn_cluster_supported(int N, int Ti);
@@ -125,6 +128,8 @@ int taco_attn_cluster_bwd_xchg_slots(int N, int Ti);
 /* which attention-BPTT kernel taco_attn_rnn_bwd runs for (N, Ti): 0 per-step kernels, 1 cluster kernel with the prenet-gradient
  * weight slices in LDS (T_in <= ~152), 2 cluster kernel with all weight slices in registers (longer inputs) */
 int taco_attn_cluster_bwd_variant(int N, int Ti);
+/* the same for taco_attn_rnn_fwd: 1 = recurrent gate weights in LDS (T_in <= ~160), 2 = in registers */
+int taco_attn_cluster_fwd_variant(int N, int Ti);
 /* residual decoder GRU(256), whole recurrence in one persistent cluster launch (csrc/gru256.hip); hoisted input
  * projection xp [N,S,768]; d = res + h when d != NULL.  xchg: >= ceil(N/2)*6*256 8-byte granule slots of scratch,
  * err: device int set to 1 if a bounded spin ever times out (results are then invalid).  N <= 128.
@@ -139,11 +144,16 @@ int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, c
 
 /* ---- optimizer: tf.clip_by_global_norm + tf.train.AdamOptimizer + Noam lr + BN UPDATE_OPS (tacotron.py:174-202) -- */
 int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream);
+/* err (optional, all three): the device error word of the persistent cluster kernels (TACO_AP_ERR); when it is non-zero at
+ * execution time the launch does nothing, so a step whose hand-off timed out never reaches the weights.
+ * taco_bn_ema also increments *global_step when it is non-NULL (one launch for UPDATE_OPS + the step counter). */
+/* grad_scale: grads (and gnorm2 = their sum of squares) hold 1/grad_scale times the gradient -- data parallel: the all-reduced
+ * SUM over replicas with grad_scale = 1/world; the clip norm and the update use grad_scale * grads (no separate averaging pass) */
 int taco_adam_step(float* params, const float* grads, float* m, float* v, long n, const double* gnorm2,
                    const int* global_step, float init_lr, int decay, float beta1, float beta2, float eps, float clip,
-                   float* info3, hipStream_t stream);
-int taco_bn_ema(float* moving, const float* batch, int n, float momentum, hipStream_t stream);
-int taco_step_inc(int* global_step, hipStream_t stream);
+                   float grad_scale, float* info3, const int* err, hipStream_t stream);
+int taco_bn_ema(float* moving, const float* batch, int n, float momentum, int* global_step, const int* err, hipStream_t stream);
+int taco_step_inc(int* global_step, const int* err, hipStream_t stream);
 int taco_scale(float* x, long n, float s, hipStream_t stream);
 
 /* pointer-table slots of taco_attn_rnn_fwd / taco_attn_rnn_bwd (all fp32 device pointers) */
@@ -196,6 +206,7 @@ enum TacoInferPtr {
     TACO_IP_OUT,                     /* out: decoder outputs                  [N,S,num_mels*r] */
     TACO_IP_H1, TACO_IP_H2,          /* scratch: GRU states, ping-pong        [2,N,256] each */
     TACO_IP_TMP,                     /* scratch                               [10,N,256] */
+    TACO_IP_STOP,                    /* int32 [1+N]: steps to keep, per-row finished flags (see taco_decoder_infer) */
     TACO_IP_COUNT
 };
 

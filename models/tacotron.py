@@ -185,6 +185,7 @@ class Tacotron():
         self.mel_outputs, self.linear_outputs, self.alignments = e.mel_outputs, e.linear_outputs, e.alignments
         self.loss, self.mel_loss, self.linear_loss = e.loss_values()
         self.loss_regularity = e.loss_regularity
+        e.check_errors()        # the stream is idle after the loss read-back: a timed-out cluster hand-off must not train on
         step = int(e.global_step.item())
         self.learning_rate = float(e.info[1].item())
         return step, self.loss, None, self.loss_regularity
@@ -197,6 +198,11 @@ class Tacotron():
 
     def load_state_dict(self, sd):
         e = self.engine
+        lay = sd.get('layout', {})
+        mine = dict(id_num=self._id_num, r=e.r)
+        if {k: int(lay.get(k, -1)) for k in mine} != mine or tuple(sd['params'].shape) != tuple(e.params.shape):
+            raise ValueError('checkpoint layout %s (%d parameters) does not match the model %s (%d parameters)'
+                             % (lay, sd['params'].numel(), mine, e.params.numel()))
         e.params.copy_(sd['params']); e.m.copy_(sd['m']); e.v.copy_(sd['v']); e.bn.copy_(sd['bn'])
         e.global_step.copy_(sd['global_step'])
 

@@ -15,6 +15,7 @@
 // members compute bit-identical softmax weights (softmax over ALL Ti positions, no memory mask: Appendix A.7).
 // Clusters never talk to each other; grid = 8 * ceil(N/2) <= 256 co-resident workgroups; spins are bounded.
 #include "attn_cluster.hpp"
+#include "xcd_granule.hpp"
 
 #define CW 8                 // workgroups per cluster
 // Diagnostic build (-DTACO_STAMP): thread 0 of workgroup 0 accumulates s_memtime deltas per phase and writes them behind
@@ -33,15 +34,24 @@
 #define PIDX(k) ((k) + ((k) >> 4) * 4)          // LDS vector layout: 4 pad floats after every 16 (bank spreading)
 #define PLEN(n) ((n) + ((n) >> 4) * 4)
 
-__device__ __forceinline__ void put_g(u64* p, unsigned epoch, float v) {
-    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// granule store: agent scope (any placement) or, when the cluster has verified that all its members sit on one XCD
+// (xcd_granule.hpp: cluster_on_one_xcd), the L2-local form that a same-XCD reader hits in the shared L2 (0.48 vs 0.64 us per
+// exchange round for 8 workgroups, scripts/dev_xchg.py)
+__device__ __forceinline__ void put_g(u64* p, unsigned epoch, float v, bool local) {
+    if (local) put_granule_xcd(p, epoch, v); else put_granule(p, epoch, v);
 }
 // indexed put with an opaque index: the 64-bit lane address is formed at the store instead of being hoisted out of the
 // step loop as a live (and then spilled) VGPR pair
-__device__ __forceinline__ void put_gi(u64* base, unsigned idx, unsigned epoch, float v) {
+__device__ __forceinline__ void put_gi(u64* base, unsigned idx, unsigned epoch, float v, bool local) {
     asm volatile("" : "+v"(idx));
-    put_g(base + idx, epoch, v);
+    put_g(base + idx, epoch, v, local);
 }
+// placement check of one cluster, broadcast to the workgroup (flag_l: an LDS int)
+__device__ __forceinline__ bool cluster_local(u64* slots, int w, int* err, int* flag_l, int tid, int allow) {
+    return cluster_shares_xcd(slots, w, CW, err, flag_l, tid, allow);
+}
+// TACO_XCD_LOCAL=0 keeps the agent-scope form everywhere (A/B timing, tests of the placement-independent path)
+static int xcd_local_allowed() { const char* e = getenv("TACO_XCD_LOCAL"); return (e && e[0] == '0') ? 0 : 1; }
 template <int NG>
 __device__ __forceinline__ void get_g(const u64* const (&ptr)[NG], unsigned epoch, float (&out)[NG], int* err) {
     u64 x[NG];
@@ -112,6 +122,12 @@ __device__ __forceinline__ void gather_vec(const u64* region, float* lds0, float
     }
 }
 
+// WLDS: the recurrent gate weights (Whg slice, 32 floats per thread) live in LDS instead of registers.  Their product with
+// h is computed off the dependent chain (while the partial scores are exchanged), so the extra LDS reads are hidden, and the
+// 32 freed VGPRs keep the kernel free of scratch spills (with all 112 weight floats in registers the loop-invariant granule
+// addresses are spilled and reloaded inside the poll loops).  The register variant remains for long inputs whose key / memory
+// tiles need the LDS (T_in > ~160).
+template <bool WLDS>
 __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -132,10 +148,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     float* rh_l = h_l + 2 * PLEN(256);
     float* u_l = rh_l + 2 * PLEN(256);            // [2][32]
     float* q_l = u_l + 64;                        // [2][32]
-    float* ep_l = q_l + 64;                       // [2*Ti] own partial scores
-    float* a_l = ep_l + ((2 * Ti + 3) & ~3);      // [2*Ti] scores -> alignments
-    float* cp_l = a_l + ((2 * Ti + 3) & ~3);      // [8][64] context partials
-    float* red_l = cp_l + 512;                    // [32] attention_v slice
+    float* an_l = q_l + 64;                       // [2*Ti] alignments (every wave of a row writes the same values)
+    float* a_l = an_l + ((2 * Ti + 3) & ~3);      // [2*Ti] scores
+    float* cp_l = a_l + ((2 * Ti + 3) & ~3);      // [16] scratch (placement verdict)
+    float* red_l = cp_l + 16;                     // [32] attention_v slice
     float* K_l = red_l + 32;                      // [2][Ti][32]
     float* M_l = K_l + 2 * Ti * 32;               // [2][Ti][32]
     for (int i = tid; i < 2 * PLEN(256) * 4 + 2 * PLEN(128); i += AT) smem[i] = 0.0f;    // ctx,p1,p2,h,rh = 0
@@ -143,7 +159,9 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
         const int c4 = i & 7, t = (i >> 3) % Ti, row = (i >> 3) / Ti;
         const long g = ((rw[row] * Ti) + t) * 256 + 32 * w + c4 * 4;
         *reinterpret_cast<float4*>(K_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.keys + g);
-        *reinterpret_cast<float4*>(M_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.mem + g);
+        // memory tile: the 16-byte chunks of row t are rotated by t & 7, i.e. column d lives at (d + 4 * (t & 7)) & 31: the
+        // context product reads (t = tp + 8 i, d) from lanes (d & 3 | tp) of a 32-lane half -> 32 distinct banks
+        *reinterpret_cast<float4*>(M_l + (row * Ti + t) * 32 + ((c4 + t) & 7) * 4) = *reinterpret_cast<const float4*>(p.mem + g);
     }
 
     // ---- register-resident weight slices
@@ -151,15 +169,22 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     const int cB = tid >> 5, pB = tid & 31;     // 16 cols x 32 parts (prenet2)
     const int cC = tid >> 3, pC = tid & 7;      // 64 cols x  8 parts (gates)
     const int gc = cC < 32 ? 32 * w + cC : 256 + 32 * w + (cC - 32);     // gate column: r_J | u_J
-    float w1[16], w2[8], wgx[16], wgh[32], wcx[8], wch[16], wqr[16];
+    float* W_l = M_l + 2 * Ti * 32;             // WLDS: [8][AT][4] Whg slice as per-thread float4 slots
+    float w1[16], w2[8], wgx[16], wgh[WLDS ? 1 : 32], wcx[8], wch[16], wqr[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) w1[k] = p.w1c[(long)(pA * 16 + k) * 256 + 32 * w + cA];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w2[k] = p.w2[(long)(pB * 8 + k) * 128 + 16 * w + cB];
 #pragma unroll
     for (int k = 0; k < 16; ++k) wgx[k] = p.wx[(long)(pC * 16 + k) * 768 + gc];
+    if (WLDS) {
 #pragma unroll
-    for (int k = 0; k < 32; ++k) wgh[k] = p.whg[(long)(pC * 32 + k) * 512 + gc];
+        for (int k = 0; k < 32; ++k) W_l[((k >> 2) * AT + tid) * 4 + (k & 3)] = p.whg[(long)(pC * 32 + k) * 512 + gc];
+        wgh[0] = 0.f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < (WLDS ? 1 : 32); ++k) wgh[k] = p.whg[(long)(pC * 32 + k) * 512 + gc];
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) wcx[k] = p.wx[(long)(pA * 8 + k) * 768 + 512 + 32 * w + cA];
 #pragma unroll
@@ -174,6 +199,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     const long per_clu = 2 * 256 * 4 + 2 * 128 + (long)CW * 2 * Ti;
     u64* X = p.xchg + (long)cl * per_clu;
     u64 *xCTX = X, *xP1 = X + 512, *xP2 = X + 1024, *xRH = X + 1280, *xH = X + 1792, *xE = X + 2304;
+    const bool local = cluster_local(p.xchg + (long)nclus * per_clu + (long)cl * CW, w, p.err, reinterpret_cast<int*>(cp_l), tid, p.xcd_local);
     float fnx0 = 0.f, fnx1 = 0.f;
     if (pA == 0) {
         fnx0 = p.f1[(unsigned)(rw[0] * S + p.s0) * 256u + 32 * w + cA];
@@ -190,6 +216,9 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     }
     __syncthreads();
     STAMP_DECL
+    float gh0 = 0.f, gh1 = 0.f;                 // h part of the gate pre-activations of the coming step (per-lane partials)
+    if constexpr (WLDS) dot2_lds<32>(h_l, h_l + PLEN(256), pC * 32, W_l, tid, gh0, gh1);
+    else dot2<32>(h_l, h_l + PLEN(256), pC * 32, wgh, gh0, gh1);
 
     for (int s = p.s0; s < p.s1; ++s) {
         const unsigned epoch = (unsigned)(s - p.s0) + 1;
@@ -208,7 +237,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             if (pA == 0) {
                 a0 = fmaxf(a0 + f0, 0.f); a1 = fmaxf(a1 + f1v, 0.f);
                 p1_l[PIDX(j)] = a0; p1_l[PLEN(256) + PIDX(j)] = a1;
-                put_g(xP1 + j, epoch, a0); put_g(xP1 + 256 + j, epoch, a1);
+                put_g(xP1 + j, epoch, a0, local); put_g(xP1 + 256 + j, epoch, a1, local);
                 if (ok[0]) p.p1[so0 * 256 + j] = a0;
                 if (ok[1]) p.p1[so1 * 256 + j] = a1;
             }
@@ -226,7 +255,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             if (pB == 0) {
                 a0 = fmaxf(a0 + b2v, 0.f); a1 = fmaxf(a1 + b2v, 0.f);
                 p2_l[PIDX(j)] = a0; p2_l[PLEN(128) + PIDX(j)] = a1;
-                put_g(xP2 + j, epoch, a0); put_g(xP2 + 128 + j, epoch, a1);
+                put_g(xP2 + j, epoch, a0, local); put_g(xP2 + 128 + j, epoch, a1, local);
                 if (ok[0]) p.p2[so0 * 128 + j] = a0;
                 if (ok[1]) p.p2[so1 * 128 + j] = a1;
             }
@@ -235,19 +264,19 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
         }
         __syncthreads();
         STAMP(4);
-        // ================= C: GRU gates =================
+        // ================= C: GRU gates (the h part of the pre-activation was computed off the chain, see F) =================
+        float cx0 = 0.f, cx1 = 0.f;                 // candidate: x part, computed while the r*h exchange is in flight
         {
             const int j = 32 * w + (cC & 31);
-            float a0 = 0.f, a1 = 0.f;
+            float a0 = gh0, a1 = gh1;
             dot2<16>(p2_l, p2_l + PLEN(128), pC * 16, wgx, a0, a1);
-            dot2<32>(h_l, h_l + PLEN(256), pC * 32, wgh, a0, a1);
             a0 = lane_reduce<8>(a0); a1 = lane_reduce<8>(a1);
             if (pC == 0) {
                 const float g0 = fast_sigmoid(a0 + bgv), g1 = fast_sigmoid(a1 + bgv);
                 if (cC < 32) {
                     const float q0 = g0 * h_l[PIDX(j)], q1 = g1 * h_l[PLEN(256) + PIDX(j)];
                     rh_l[PIDX(j)] = q0; rh_l[PLEN(256) + PIDX(j)] = q1;
-                    put_g(xRH + j, epoch, q0); put_g(xRH + 256 + j, epoch, q1);
+                    put_g(xRH + j, epoch, q0, local); put_g(xRH + 256 + j, epoch, q1, local);
                     if (ok[0]) { p.r[so0 * 256 + j] = g0; p.rh[so0 * 256 + j] = q0; }
                     if (ok[1]) { p.r[so1 * 256 + j] = g1; p.rh[so1 * 256 + j] = q1; }
                 } else {
@@ -257,6 +286,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 }
             }
             STAMP(5);
+            dot2<8>(p2_l, p2_l + PLEN(128), pA * 8, wcx, cx0, cx1);
             gather_vec<32>(xRH, rh_l, rh_l + PLEN(256), w, epoch, tid, p.err);
         }
         __syncthreads();
@@ -264,8 +294,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
         // ================= D: candidate + new state =================
         {
             const int j = 32 * w + cA;
-            float a0 = 0.f, a1 = 0.f;
-            dot2<8>(p2_l, p2_l + PLEN(128), pA * 8, wcx, a0, a1);
+            float a0 = cx0, a1 = cx1;
             dot2<16>(rh_l, rh_l + PLEN(256), pA * 16, wch, a0, a1);
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
             if (pA == 0) {
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 const float hn0 = u0 * h_l[PIDX(j)] + (1.f - u0) * c0;
                 const float hn1 = u1 * h_l[PLEN(256) + PIDX(j)] + (1.f - u1) * c1;
                 h_l[PIDX(j)] = hn0; h_l[PLEN(256) + PIDX(j)] = hn1;
-                put_g(xH + j, epoch, hn0); put_g(xH + 256 + j, epoch, hn1);
+                put_g(xH + j, epoch, hn0, local); put_g(xH + 256 + j, epoch, hn1, local);
                 if (ok[0]) { p.c[so0 * 256 + j] = c0; p.hc[so0 * 512 + j] = hn0; }
                 if (ok[1]) { p.c[so1 * 256 + j] = c1; p.hc[so1 * 512 + j] = hn1; }
             }
@@ -297,8 +326,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
         __syncthreads();
         STAMP(9);
         // ================= F: partial scores over this workgroup's 32 dims, all t =================
-        for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
-            const int half = tid & 1;
+        // pass 1: own partials, published (and parked in a_l); then work that is off the dependent chain; pass 2: gather + reduce
+        int tf = threadIdx.x;
+        asm volatile("" : "+v"(tf));               // opaque per step (see above)
+        for (int i = tf >> 1; i < 2 * Ti; i += AT / 2) {
+            const int half = tf & 1;
             const int row = i >= Ti;
             const float* kp = K_l + i * 32 + half * 16;
             const float* qp = q_l + row * 32 + half * 16;
@@ -313,9 +345,19 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 e = fmaf(vv.z, fast_tanh(kv.z + qv.z), e); e = fmaf(vv.w, fast_tanh(kv.w + qv.w), e);
             }
             e = dpp_add<0xB1>(e);                                  // both lanes of the pair now hold this workgroup's partial
-            if (half == 0) put_g(xE + (long)w * 2 * Ti + i, epoch, e);
+            if (half == 0) { put_g(xE + (long)w * 2 * Ti + i, epoch, e, local); a_l[i] = e; }
+        }
+        // off the dependent chain, while the partial scores travel: the h part of the NEXT step's gate pre-activations
+        // (h_l holds the complete h_s since the barrier after D and is not written again before the next step's D)
+        gh0 = 0.f; gh1 = 0.f;
+        if constexpr (WLDS) dot2_lds<32>(h_l, h_l + PLEN(256), (tf & 7) * 32, W_l, tf, gh0, gh1);
+        else dot2<32>(h_l, h_l + PLEN(256), pC * 32, wgh, gh0, gh1);
+        asm volatile("" : "+v"(tf));
+        for (int i = tf >> 1; i < 2 * Ti; i += AT / 2) {
+            const int half = tf & 1;
+            const float e = a_l[i];                                // written by this lane pair above (same wave: in order)
             // gather + reduce the 8 partials of (row,t) in workgroup order (bit-identical in all members); the own
-            // partial comes from the register, its slot is replaced by a dummy peer slot in the poll
+            // partial comes from LDS, its slot is replaced by a dummy peer slot in the poll
             float val[4];
             const u64* ptr[4];
 #pragma unroll
@@ -334,68 +376,69 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
         __syncthreads();
         STAMP(10);
         STAMP(11);
-        // ================= G: softmax over all Ti (wave 0 -> row 0, wave 1 -> row 1) =================
-        if (tid < 128) {
-            const int row = tid >> 6, lane = tid & 63;
-            float* ar = a_l + row * Ti;
+        // ================= G+H: softmax and context slice, one pass per wave, no barrier in between =================
+        // Wave v works on row v >> 2 and context dims 8 (v & 3) .. +8.  Every wave of a row recomputes that row's softmax from
+        // the (bit-identical) total scores -- 2..8 exponentials per lane -- and writes the alignments to an_l; the four waves of
+        // a row write the same bits, and each reads back only after its own writes (same-wave LDS ordering), so no workgroup
+        // barrier separates softmax and context product.  ctx[row][d] = sum_t a[t] * mem[t][d]: lane (d & 7 | tp) sums
+        // t = tp, tp + 8, ... and the 8 tp lanes are combined with DPP adds.
+        {
+            int tq = threadIdx.x;
+            asm volatile("" : "+v"(tq));           // opaque: nothing lane-derived is hoisted out of the step loop (it would spill)
+            const int wv = tq >> 6, lane = tq & 63;
+            const int row = wv >> 2;
+            const float* er = a_l + row * Ti;
+            float* ar = an_l + row * Ti;
             float ev[8];                                   // Ti <= 512 values per row live in registers
             float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const int t = lane + 64 * i; ev[i] = t < Ti ? ar[t] : -INFINITY; mx = fmaxf(mx, ev[i]); }
+            for (int i = 0; i < 8; ++i) { const int t = lane + 64 * i; ev[i] = t < Ti ? er[t] : -INFINITY; mx = fmaxf(mx, ev[i]); }
             mx = wave_max_fast(mx);
             float sm = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { ev[i] = __builtin_amdgcn_exp2f((ev[i] - mx) * 1.4426950408889634f); sm += ev[i]; }
             sm = wave_sum_fast(sm);
             const float inv = __builtin_amdgcn_rcpf(sm);
+            const unsigned arow = (row ? so1 : so0) * (unsigned)Ti;
+            const bool wr = (wv & 3) == 0 && (lane & 7) == w && ok[row];       // member w stores t = w, w + 8, ... to HBM
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const int t = lane + 64 * i; if (t < Ti) ar[t] = ev[i] * inv; }
-        }
-        __syncthreads();
-        STAMP(12);
-        // alignments to HBM: member w writes t = w, w+8, ...
-        for (int i = tid; i < 2 * Ti; i += AT) {
-            const int row = i >= Ti, t = i - row * Ti;
-            if ((t & 7) == w && ok[row]) p.align[(row ? so1 : so0) * (unsigned)Ti + t] = a_l[i];
-        }
-        // ================= H: context slice: ctx[row][d] = sum_t a[t] * mem[t][d] =================
-        {
-            const int row = tid >> 8, tp = (tid >> 5) & 7, d = tid & 31;
-            const float* ar = a_l + row * Ti;
-            const float* mr = M_l + row * Ti * 32 + d;
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            int t = tp;
-            for (; t + 24 < Ti; t += 32) {                 // 4 independent LDS-load/FMA chains in flight
-                acc0 = fmaf(ar[t], mr[t * 32], acc0); acc1 = fmaf(ar[t + 8], mr[(t + 8) * 32], acc1);
-                acc2 = fmaf(ar[t + 16], mr[(t + 16) * 32], acc2); acc3 = fmaf(ar[t + 24], mr[(t + 24) * 32], acc3);
+            for (int i = 0; i < 8; ++i) {
+                const int t = lane + 64 * i;
+                if (t < Ti) { const float av = ev[i] * inv; ar[t] = av; if (wr) p.align[arow + t] = av; }
             }
-            for (; t < Ti; t += 8) acc0 = fmaf(ar[t], mr[t * 32], acc0);
-            cp_l[tp * 64 + row * 32 + d] = (acc0 + acc1) + (acc2 + acc3);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int row = tid >> 5, d = tid & 31, j = 32 * w + d;
-            float cx = 0.f;
-#pragma unroll
-            for (int tp = 0; tp < 8; ++tp) cx += cp_l[tp * 64 + tid];
-            ctx_l[row * PLEN(256) + PIDX(j)] = cx;
-            put_g(xCTX + row * 256 + j, epoch, cx);
-            if (ok[row]) p.hc[(row ? so1 : so0) * 512u + 256u + j] = cx;
+            const int tp = lane & 7, d = 8 * (wv & 3) + (lane >> 3);
+            const float* mr = M_l + row * Ti * 32;
+            float acc0 = 0.f, acc1 = 0.f;
+            int t = tp;
+            for (; t + 8 < Ti; t += 16) {
+                acc0 = fmaf(ar[t], mr[t * 32 + ((d + 4 * tp) & 31)], acc0);
+                acc1 = fmaf(ar[t + 8], mr[(t + 8) * 32 + ((d + 4 * tp) & 31)], acc1);
+            }
+            if (t < Ti) acc0 = fmaf(ar[t], mr[t * 32 + ((d + 4 * tp) & 31)], acc0);
+            const float cx = group_sum<8>(acc0 + acc1);
+            if (tp == 0) {
+                const int j = 32 * w + d;
+                ctx_l[row * PLEN(256) + PIDX(j)] = cx;
+                put_g(xCTX + row * 256 + j, epoch, cx, local);
+                if (ok[row]) p.hc[(row ? so1 : so0) * 512u + 256u + j] = cx;
+            }
         }
         STAMP(13);
         gather_vec<32>(xCTX, ctx_l, ctx_l + PLEN(256), w, epoch, tid, p.err);
         __syncthreads();
         STAMP(14);
     }
-    STAMP_OUT(p.xchg + (long)nclus * per_clu);
+    STAMP_OUT(p.xchg + (long)nclus * (per_clu + CW));
 }
 
+// per cluster: the exchange regions + CW placement granules; + 16 diagnostic stamp slots at the very end
 extern "C" int taco_attn_cluster_xchg_slots(int N, int Ti) {
-    return ((N + 1) / 2) * (2 * 256 * 4 + 2 * 128 + CW * 2 * Ti) + 16;     // + 16 diagnostic stamp slots
+    return ((N + 1) / 2) * (2 * 256 * 4 + 2 * 128 + CW * 2 * Ti + CW) + 16;
 }
 
-static size_t attn_cluster_smem(int Ti) {
-    size_t f = 2 * PLEN(256) * 4 + 2 * PLEN(128) + 64 + 64 + 2 * ((2 * Ti + 3) & ~3) + 512 + 32 + (size_t)4 * Ti * 32;
+static size_t attn_cluster_smem(int Ti, bool wlds = false) {
+    size_t f = 2 * PLEN(256) * 4 + 2 * PLEN(128) + 64 + 64 + 2 * ((2 * Ti + 3) & ~3) + 16 + 32 + (size_t)4 * Ti * 32 +
+               (wlds ? 8 * AT * 4 : 0);
     return f * sizeof(float);
 }
 
@@ -406,16 +449,29 @@ extern "C" int taco_attn_cluster_supported(int N, int Ti) {
             Ti >= 1 && Ti <= 512) ? 1 : 0;
 }
 
+// which forward kernel a (N, Ti) launch runs: 0 = per-step kernels, 1 = attn_cluster_fwd_k<true> (Whg slice in LDS), 2 = <false>
+extern "C" int taco_attn_cluster_fwd_variant(int N, int Ti) {
+    if (!taco_attn_cluster_supported(N, Ti)) return 0;
+    const char* e = getenv("TACO_ATTN_FWD_NO_WLDS");
+    const bool no_wlds = e && e[0] && e[0] != '0';
+    return (!no_wlds && attn_cluster_smem(Ti, true) <= 160 * 1024) ? 1 : 2;
+}
+
 int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
-    const size_t smem = attn_cluster_smem(p.Ti);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_cluster_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_cluster_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_cluster_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return TACO_EINVAL;
         attr_set = true;
     }
     if (hipMemsetAsync(p.xchg, 0, (size_t)(taco_attn_cluster_xchg_slots(p.N, p.Ti) - 16) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
-    hipLaunchKernelGGL(attn_cluster_fwd_k, dim3(CW * ((p.N + 1) / 2)), dim3(AT), smem, st, p);
+    AttnClu q = p;
+    q.xcd_local = xcd_local_allowed();
+    if (taco_attn_cluster_fwd_variant(p.N, p.Ti) == 1)
+        hipLaunchKernelGGL(attn_cluster_fwd_k<true>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_smem(p.Ti, true), st, q);
+    else
+        hipLaunchKernelGGL(attn_cluster_fwd_k<false>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_smem(p.Ti, false), st, q);
     TACO_RETURN_LAST();
 }
 
@@ -536,6 +592,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     const long per_clu = (long)CW * 2 * Ti + 2 * 256 * 5 + 2 * 128;
     u64* X = p.xchg + (long)cl * per_clu;
     u64 *xDQ = X, *xDCP = X + 512, *xDGR = X + 1024, *xDGU = X + 1536, *xDP2 = X + 2048, *xDP1 = X + 2304, *xDA = X + 2816;
+    const bool local = cluster_local(p.xchg + (long)nclus * per_clu + (long)cl * CW, w, p.err, reinterpret_cast<int*>(cp_l), tid, p.xcd_local);
 
     float dhc0 = 0.f, dhc1 = 0.f;      // dh carry   (owner lanes: pA == 0, index jA)
     float dcc0 = 0.f, dcc1 = 0.f;      // dctx carry (owner lanes: pA == 0, index jA)
@@ -606,7 +663,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 e = fmaf(mv.x, gv.x, e); e = fmaf(mv.y, gv.y, e); e = fmaf(mv.z, gv.z, e); e = fmaf(mv.w, gv.w, e);
             }
             e = dpp_add<0xB1>(e);
-            if (half == 0) put_gi(xDA, (unsigned)(w * 2 * Ti + i), epoch, e);
+            if (half == 0) put_gi(xDA, (unsigned)(w * 2 * Ti + i), epoch, e, local);
             float val[4];
             const u64* ptr[4];
 #pragma unroll
@@ -664,7 +721,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
 #pragma unroll
             for (int tp = 0; tp < 8; ++tp) x += cp_l[tp * 64 + tid];
             dq_l[row * PLEN(256) + PIDX(j)] = x;
-            put_gi(xDQ, (unsigned)(row * 256 + j), epoch, x);
+            put_gi(xDQ, (unsigned)(row * 256 + j), epoch, x, local);
             if (ok[row]) p.dq[so[row] * 256 + j] = x;
         }
         gather_vec<32>(xDQ, dq_l, dq_l + PLEN(256), w, epoch, tid, p.err);
@@ -683,7 +740,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     dhd[b] = dhT[b] * u_[b];
                     const float dcp = dhT[b] * (1.f - u_[b]) * (1.f - c_[b] * c_[b]);
                     dxp_l[b * PLEN(768) + PIDX(512 + jA)] = dcp;
-                    put_gi(xDCP, (unsigned)(b * 256 + jA), epoch, dcp);
+                    put_gi(xDCP, (unsigned)(b * 256 + jA), epoch, dcp, local);
                     if (ok[b]) p.dxp[so[b] * 768 + 512 + jA] = dcp;
                 }
             }
@@ -705,8 +762,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     dhp[b] = dhd[b] + drh[b] * r_[b];
                     dxp_l[b * PLEN(768) + PIDX(jA)] = dgr;
                     dxp_l[b * PLEN(768) + PIDX(256 + jA)] = dgu;
-                    put_gi(xDGR, (unsigned)(b * 256 + jA), epoch, dgr);
-                    put_gi(xDGU, (unsigned)(b * 256 + jA), epoch, dgu);
+                    put_gi(xDGR, (unsigned)(b * 256 + jA), epoch, dgr, local);
+                    put_gi(xDGU, (unsigned)(b * 256 + jA), epoch, dgu, local);
                     if (ok[b]) { p.dxp[so[b] * 768 + jA] = dgr; p.dxp[so[b] * 768 + 256 + jA] = dgu; }
                 }
             }
@@ -740,7 +797,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             if (pB == 0) {
                 b0 = p2v[0] > 0.f ? b0 : 0.f; b1 = p2v[1] > 0.f ? b1 : 0.f;
                 dp2_l[PIDX(jB)] = b0; dp2_l[PLEN(128) + PIDX(jB)] = b1;
-                put_gi(xDP2, (unsigned)(jB), epoch, b0); put_gi(xDP2, (unsigned)(128 + jB), epoch, b1);
+                put_gi(xDP2, (unsigned)(jB), epoch, b0, local); put_gi(xDP2, (unsigned)(128 + jB), epoch, b1, local);
                 if (ok[0]) p.dp2[so[0] * 128 + jB] = b0;
                 if (ok[1]) p.dp2[so[1] * 128 + jB] = b1;
             }
@@ -756,7 +813,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             if (pA == 0) {
                 a0 = p1v[0] > 0.f ? a0 : 0.f; a1 = p1v[1] > 0.f ? a1 : 0.f;
                 dp1_l[PIDX(jA)] = a0; dp1_l[PLEN(256) + PIDX(jA)] = a1;
-                put_gi(xDP1, (unsigned)(jA), epoch, a0); put_gi(xDP1, (unsigned)(256 + jA), epoch, a1);
+                put_gi(xDP1, (unsigned)(jA), epoch, a0, local); put_gi(xDP1, (unsigned)(256 + jA), epoch, a1, local);
                 if (ok[0]) p.dp1[so[0] * 256 + jA] = a0;
                 if (ok[1]) p.dp1[so[1] * 256 + jA] = a1;
             }
@@ -829,7 +886,7 @@ extern "C" int taco_attn_cluster_bwd_variant(int N, int Ti) {
 }
 
 extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
-    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128);
+    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128 + CW);       // + CW placement granules per cluster
 }
 
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
@@ -842,10 +899,12 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
     }
     if (attn_cluster_bwd_smem(p.Ti, false) > 160 * 1024) return TACO_EINVAL;
     if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    AttnCluB q = p;
+    q.xcd_local = xcd_local_allowed();
     if (taco_attn_cluster_bwd_variant(p.N, p.Ti) == 1)
-        hipLaunchKernelGGL(attn_cluster_bwd_k<true>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, true), st, p);
+        hipLaunchKernelGGL(attn_cluster_bwd_k<true>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, true), st, q);
     else
-        hipLaunchKernelGGL(attn_cluster_bwd_k<false>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, false), st, p);
+        hipLaunchKernelGGL(attn_cluster_bwd_k<false>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, false), st, q);
     if (p.s0 == 0)       // all chunks done: reduce over the S steps
         hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3(p.Ti, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
                            dkeys, dmem, dvpart, p.S, p.Ti);

@@ -7,6 +7,7 @@ struct AttnClu {
     float *p1, *p2, *r, *u, *c, *rh, *hc, *q, *align;
     u64* xchg; int* err;
     int N, S, Ti, s0, s1;
+    int xcd_local;                   // 1: clusters whose members share an XCD use the L2-local granule form (set by the launcher)
 };
 int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st);
 struct AttnCluB {
@@ -17,5 +18,6 @@ struct AttnCluB {
     float *dhcarry, *dctxcarry;      // [N,256] each: state handed between chunk launches
     u64* xchg; int* err;
     int N, S, Ti, s0, s1;
+    int xcd_local;
 };
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st);

@@ -527,14 +527,32 @@ extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipSt
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Free-running inference decoder (reference models/helpers.py:7-38 TacoTestHelper + tacotron.py:86-94): the last of the r
-// predicted frames is fed back, so nothing can be hoisted; one launch per dependent stage (13 per step).  The reference
-// stops when a whole r-frame output is EXACTLY zero (never in practice) or at max_iters; this runs `S` steps.
-// ptrs indexed by enum TacoInferPtr, dims = {N, S, Ti, r, num_mels}.
+// predicted frames is fed back, so nothing can be hoisted; one launch per dependent stage (13 per step).
+// Stop condition (helpers.py:32-38 + dynamic_decode): a row is finished once a whole r-frame output of it is EXACTLY zero
+// (sticky), decoding ends after the first step at which every row is finished, or at max_iters.  infer_stop_k keeps the
+// per-row flags and the step count on the device (TACO_IP_STOP); the host enqueues the steps [s0, s1) of a launch
+// unconditionally and reads the count between launches (Engine.infer), so nothing here synchronises.
+// ptrs indexed by enum TacoInferPtr, dims = {N, S, Ti, r, num_mels, s0, s1}.
 // ---------------------------------------------------------------------------------------------------------------------
+// stop[0] = number of decoder steps to keep (initialised to S by the caller), stop[1 + n] = row n finished
+__global__ void infer_stop_k(const float* __restrict__ out, long ld, int no, int N, int s, int S, int* __restrict__ stop) {
+    __shared__ int all_done;
+    if (threadIdx.x == 0) all_done = 1;
+    __syncthreads();
+    for (int n = threadIdx.x >> 6; n < N; n += blockDim.x >> 6) {          // one wave per row
+        bool zero = true;
+        for (int j = threadIdx.x & 63; j < no; j += 64) zero = zero && (out[n * ld + j] == 0.0f);
+        const bool fin = (__all(zero) != 0) || stop[1 + n] != 0;
+        if ((threadIdx.x & 63) == 0) { stop[1 + n] = fin ? 1 : 0; if (!fin) all_done = 0; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && all_done && stop[0] == S) stop[0] = s + 1;
+}
+
 extern "C" int taco_decoder_infer(const void* const* ptrs, const int* dims, hipStream_t st) {
     if (!ptrs || !dims) return TACO_EINVAL;
-    const int N = dims[0], S = dims[1], Ti = dims[2], r = dims[3], nm = dims[4];
-    if (N <= 0 || S <= 0 || Ti <= 0 || r <= 0 || nm <= 0 || (nm & 3)) return TACO_EINVAL;
+    const int N = dims[0], S = dims[1], Ti = dims[2], r = dims[3], nm = dims[4], s_lo = dims[5], s_hi = dims[6];
+    if (N <= 0 || S <= 0 || Ti <= 0 || r <= 0 || nm <= 0 || (nm & 3) || s_lo < 0 || s_hi > S || s_lo >= s_hi) return TACO_EINVAL;
     for (int i = 0; i < TACO_IP_COUNT; ++i) if (!ptrs[i]) return TACO_EINVAL;
     auto F = [&](int i) { return (const float*)ptrs[i]; };
     auto G = [&](int i) { return (float*)const_cast<void*>(ptrs[i]); };
@@ -560,7 +578,7 @@ extern "C" int taco_decoder_infer(const void* const* ptrs, const int* dims, hipS
     float* T = G(TACO_IP_TMP);            // [10][N,256] step scratch: p1, p2(128), r, u, c, rh, q, y, d1, d2
     float *p1 = T, *p2 = T + (long)N * 256, *R = T + 2L * N * 256, *U = T + 3L * N * 256, *C = T + 4L * N * 256,
           *RH = T + 5L * N * 256, *Q = T + 6L * N * 256, *Y = T + 7L * N * 256, *D1 = T + 8L * N * 256, *D2 = T + 9L * N * 256;
-    for (int s = 0; s < S; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         const bool first = s == 0;
         float* hc_s = G(TACO_IP_HC) + (long)s * 512;                 // [N] rows, ld S*512
         const float* hprev = first ? zeros : hc_s - 512;
@@ -605,6 +623,8 @@ extern "C" int taco_decoder_infer(const void* const* ptrs, const int* dims, hipS
         k = Skinny{}; k.A0 = D2; k.lda0 = 256; k.K0 = 256; k.B0 = F(TACO_IP_WO); k.ldb0 = no;
         k.M = N; k.N = no; k.mode = M_LINEAR; k.p[0] = F(TACO_IP_BO); k.o[0] = G(TACO_IP_OUT) + (long)s * no; k.ldo[0] = S * no;
         launch_skinny(k, st);
+        hipLaunchKernelGGL(infer_stop_k, dim3(1), dim3(256), 0, st, F(TACO_IP_OUT) + (long)s * no, (long)S * no, no, N, s, S,
+                           (int*)const_cast<void*>(ptrs[TACO_IP_STOP]));
     }
     TACO_RETURN_LAST();
 }

@@ -15,16 +15,17 @@
 //
 // GRU semantics: tf.contrib.rnn.GRUCell, input projection hoisted (xp = x.Wx + b).
 #include "common.hpp"
+#include "xcd_granule.hpp"
 
-typedef unsigned long long u64;
 #define HD 256
 #define GT2 512
 #define SPIN_LIMIT (1 << 22)
 #define QIDX(k) ((k) + ((k) >> 5) * 4)       // LDS vectors: 4 pad floats after every 32
 #define QLEN(n) ((n) + ((n) >> 5) * 4)
 
-__device__ __forceinline__ void put_granule(u64* p, unsigned epoch, float v) {
-    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// agent-scope granule, or the L2-local form once the cluster has verified that its 4 members share an XCD (xcd_granule.hpp)
+__device__ __forceinline__ void put_gr(u64* p, unsigned epoch, float v, bool local) {
+    if (local) put_granule_xcd(p, epoch, v); else put_granule(p, epoch, v);
 }
 // poll NG granules together: all loads are issued back-to-back, so a thread pays ONE round trip per poll pass
 template <int NG>
@@ -44,6 +45,8 @@ __device__ __forceinline__ void get_granules(const u64* const (&ptr)[NG], unsign
     for (int i = 0; i < NG; ++i) out[i] = __uint_as_float((unsigned)x[i]);
 }
 
+static int gru_xcd_local_allowed() { const char* e = getenv("TACO_XCD_LOCAL"); return (e && e[0] == '0') ? 0 : 1; }
+
 struct Gru256 {
     const float* xp;      // [N,S,768] hoisted input projection (+bias): r | u | c
     const float* whg;     // [256,512]
@@ -54,6 +57,7 @@ struct Gru256 {
     int* err;
     int N, S;
     int s0, s1;           // step range [s0, s1) of this launch (chunked pipelining); state enters / leaves through h / carry
+    int xcd_local;        // 1: clusters whose members share an XCD use the L2-local granule form
     // backward
     const float* dout;    // [N,S,256]
     float* dxp;           // [N,S,768]
@@ -110,6 +114,8 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
     __syncthreads();
     u64* xr = p.xchg + ((long)cl * 2) * HD;                               // rh granules  [2][256]
     u64* xh = p.xchg + ((long)nclus * 2 + (long)cl * 2) * HD;             // h' granules
+    __shared__ int local_s;
+    const bool local = cluster_shares_xcd(p.xchg + (long)nclus * 4 * HD + (long)cl * 4, w, 4, p.err, &local_s, tid, p.xcd_local);
     const int j_own = 64 * w + (gcol & 63);                               // hidden index of this thread's gate column
     const int jc = 64 * w + ccol;                                         // hidden index of the candidate column
 
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
             if (gcol < 64) {
                 const float q0 = g0 * h_l[0][QIDX(j_own)], q1 = g1 * h_l[1][QIDX(j_own)];
                 rh_l[0][QIDX(j_own)] = q0; rh_l[1][QIDX(j_own)] = q1;
-                put_granule(xr + j_own, epoch, q0);
-                put_granule(xr + HD + j_own, epoch, q1);
+                put_gr(xr + j_own, epoch, q0, local);
+                put_gr(xr + HD + j_own, epoch, q1, local);
                 if (ok0) { p.r[o0 * 256u + j_own] = g0; p.rh[o0 * 256u + j_own] = q0; }
                 if (ok1) { p.r[o1 * 256u + j_own] = g1; p.rh[o1 * 256u + j_own] = q1; }
             } else {
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
             const float hn0 = u0 * h_l[0][QIDX(jc)] + (1.0f - u0) * cc0;
             const float hn1 = u1 * h_l[1][QIDX(jc)] + (1.0f - u1) * cc1;
             h_l[0][QIDX(jc)] = hn0; h_l[1][QIDX(jc)] = hn1;
-            put_granule(xh + jc, epoch, hn0);
-            put_granule(xh + HD + jc, epoch, hn1);
+            put_gr(xh + jc, epoch, hn0, local);
+            put_gr(xh + HD + jc, epoch, hn1, local);
             if (ok0) {
                 p.c[o0 * 256u + jc] = cc0; p.h[o0 * 256u + jc] = hn0;
                 if (p.d) p.d[o0 * 256u + jc] = p.res[o0 * 256u + jc] + hn0;
@@ -231,6 +237,8 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
     u64* xc = p.xchg + ((long)cl * 2) * HD;                                  // dcp granules [2][256]
     u64* xgr = p.xchg + ((long)nclus * 2) * HD + ((long)cl * 2) * HD;        // dg_r granules [2][256]
     u64* xgu = p.xchg + ((long)nclus * 4) * HD + ((long)cl * 2) * HD;        // dg_u granules [2][256]
+    __shared__ int local_s;
+    const bool local = cluster_shares_xcd(p.xchg + (long)nclus * 6 * HD + (long)cl * 4, w, 4, p.err, &local_s, tid, p.xcd_local);
     const bool owner = j8 == 0;
 
     float dhT[2] = {0.f, 0.f}, dhn[2] = {0.f, 0.f};
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
                 dhd[b] = dhT[b] * u_[b];
                 const float dcp = dhT[b] * (1.0f - u_[b]) * (1.0f - c_[b] * c_[b]);
                 dx_l[b][QIDX(512 + k_own)] = dcp;
-                put_granule(xc + b * HD + k_own, epoch, dcp);
+                put_gr(xc + b * HD + k_own, epoch, dcp, local);
                 if (ok[b]) p.dxp[o[b] * 768u + 512u + k_own] = dcp;
             }
             if (s > p.s0) {                                // prefetch step s-1
@@ -304,8 +312,8 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
                 dhp[b] = dhd[b] + drh[b] * r_[b];
                 dx_l[b][QIDX(k_own)] = dgr;
                 dx_l[b][QIDX(HD + k_own)] = dgu;
-                put_granule(xgr + b * HD + k_own, epoch, dgr);
-                put_granule(xgu + b * HD + k_own, epoch, dgu);
+                put_gr(xgr + b * HD + k_own, epoch, dgr, local);
+                put_gr(xgu + b * HD + k_own, epoch, dgu, local);
                 if (ok[b]) { p.dxp[o[b] * 768u + k_own] = dgr; p.dxp[o[b] * 768u + 256u + k_own] = dgu; }
             }
         }
@@ -361,10 +369,10 @@ extern "C" int taco_gru256_seq_fwd(const float* xp, const float* whg, const floa
     if (d && !res) return TACO_EINVAL;
     if (gru256_grid(N) > 256) return TACO_EINVAL;           // all workgroups must be co-resident
     const int nclus = (N + 1) / 2;
-    if (hipMemsetAsync(xchg, 0, (size_t)nclus * 2 * 2 * HD * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    if (hipMemsetAsync(xchg, 0, (size_t)nclus * (2 * 2 * HD + 4) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;     // + placement granules
     Gru256 p{};
     p.xp = xp; p.whg = whg; p.whc = whc; p.res = res; p.r = r; p.u = u; p.c = c; p.rh = rh; p.h = h; p.d = d;
-    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1;
+    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1; p.xcd_local = gru_xcd_local_allowed();
     hipLaunchKernelGGL(gru256_cluster_fwd_k, dim3(gru256_grid(N)), dim3(GT2), 0, st, p);
     TACO_RETURN_LAST();
 }
@@ -376,11 +384,11 @@ extern "C" int taco_gru256_seq_bwd(const float* dout, const float* whg, const fl
     if (s0 < 0 || s1 > S || s0 >= s1) return TACO_EINVAL;
     if (gru256_grid(N) > 256) return TACO_EINVAL;
     const int nclus = (N + 1) / 2;
-    if (hipMemsetAsync(xchg, 0, (size_t)nclus * 2 * 3 * HD * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    if (hipMemsetAsync(xchg, 0, (size_t)nclus * (2 * 3 * HD + 4) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;     // + placement granules
     Gru256 p{};
     p.dout = dout; p.whg = whg; p.whc = whc; p.r = const_cast<float*>(r); p.u = const_cast<float*>(u);
     p.c = const_cast<float*>(c); p.h = const_cast<float*>(h); p.dxp = dxp;
-    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1; p.carry = carry;
+    p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1; p.carry = carry; p.xcd_local = gru_xcd_local_allowed();
     hipLaunchKernelGGL(gru256_cluster_bwd_k, dim3(gru256_grid(N)), dim3(GT2), 0, st, p);
     TACO_RETURN_LAST();
 }

@@ -27,18 +27,21 @@ __global__ void sumsq_k(const float* __restrict__ x, long n4, long n, double* __
 struct AdamArgs {
     float* p; const float* g; float* m; float* v; long n4;
     const double* gnorm2; const int* step;
-    float init_lr, beta1, beta2, eps, clip; int decay;
+    float init_lr, beta1, beta2, eps, clip, gscale; int decay;
     float* info;     // optional [3]: global_norm, learning_rate, scale (written by thread 0)
+    const int* err;  // optional: device error word of the persistent cluster kernels; non-zero = this step's gradients are invalid
 };
 
 __global__ void adam_k(AdamArgs a) {
+    if (a.err && *a.err != 0) return;            // a hand-off timed out somewhere in this step: leave the weights untouched
     const double t = (double)(*a.step + 1);
     double lr = a.init_lr;
     if (a.decay) lr = (double)a.init_lr * sqrt(4000.0) * fmin(t * pow(4000.0, -1.5), 1.0 / sqrt(t));   // tacotron.py:198-202
     const float lr_t = (float)(lr * sqrt(1.0 - pow((double)a.beta2, t)) / (1.0 - pow((double)a.beta1, t)));
-    const float norm = (float)sqrt(*a.gnorm2);
-    const float scale = a.clip / fmaxf(norm, a.clip);      // tf.clip_by_global_norm
-    if (a.info && blockIdx.x == 0 && threadIdx.x == 0) { a.info[0] = norm; a.info[1] = (float)lr; a.info[2] = scale; }
+    // g holds gscale^-1 times the gradient (data parallel: the SUM over replicas, gscale = 1/world): norm and update use gscale*g
+    const float norm = (float)sqrt(*a.gnorm2) * a.gscale;
+    const float scale = a.clip / fmaxf(norm, a.clip) * a.gscale;      // tf.clip_by_global_norm
+    if (a.info && blockIdx.x == 0 && threadIdx.x == 0) { a.info[0] = norm; a.info[1] = (float)lr; a.info[2] = a.clip / fmaxf(norm, a.clip); }
     const float b1 = a.beta1, b2 = a.beta2, eps = a.eps;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.n4; i += (long)gridDim.x * blockDim.x) {
         float4 g = reinterpret_cast<const float4*>(a.g)[i];
@@ -57,12 +60,15 @@ __global__ void adam_k(AdamArgs a) {
     }
 }
 
-__global__ void bn_ema_k(float* __restrict__ mov, const float* __restrict__ batch, int n, float momentum) {
+// UPDATE_OPS of the batch norms + (optionally) global_step += 1 in the same launch; both skipped when *err != 0
+__global__ void bn_ema_k(float* __restrict__ mov, const float* __restrict__ batch, int n, float momentum, int* step, const int* err) {
+    if (err && *err != 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) mov[i] -= (mov[i] - batch[i]) * (1.0f - momentum);
+    if (step && i == 0) *step += 1;
 }
 
-__global__ void step_inc_k(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+__global__ void step_inc_k(int* step, const int* err) { if (threadIdx.x == 0 && blockIdx.x == 0 && !(err && *err != 0)) *step += 1; }
 
 __global__ void scale_k(float* __restrict__ x, long n4, float s) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -82,21 +88,24 @@ extern "C" int taco_sumsq(const float* x, long n, double* acc, hipStream_t strea
 
 extern "C" int taco_adam_step(float* params, const float* grads, float* m, float* v, long n, const double* gnorm2,
                               const int* global_step, float init_lr, int decay, float beta1, float beta2, float eps, float clip,
-                              float* info3, hipStream_t stream) {
-    if (!params || !grads || !m || !v || !gnorm2 || !global_step || (n & 3)) return TACO_EINVAL;
-    AdamArgs a{params, grads, m, v, n / 4, gnorm2, global_step, init_lr, beta1, beta2, eps, clip, decay, info3};
+                              float grad_scale, float* info3, const int* err, hipStream_t stream) {
+    if (!params || !grads || !m || !v || !gnorm2 || !global_step || (n & 3) || !(grad_scale > 0.0f)) return TACO_EINVAL;
+    AdamArgs a{params, grads, m, v, n / 4, gnorm2, global_step, init_lr, beta1, beta2, eps, clip, grad_scale, decay, info3, err};
     long g = (a.n4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
     hipLaunchKernelGGL(adam_k, dim3((int)g), dim3(256), 0, stream, a);
     TACO_RETURN_LAST();
 }
 
-extern "C" int taco_bn_ema(float* moving, const float* batch, int n, float momentum, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_ema_k, dim3(cdiv(n, 256)), dim3(256), 0, stream, moving, batch, n, momentum);
+extern "C" int taco_bn_ema(float* moving, const float* batch, int n, float momentum, int* global_step, const int* err,
+                           hipStream_t stream) {
+    if (!moving || !batch || n < 1) return TACO_EINVAL;
+    hipLaunchKernelGGL(bn_ema_k, dim3(cdiv(n, 256)), dim3(256), 0, stream, moving, batch, n, momentum, global_step, err);
     TACO_RETURN_LAST();
 }
 
-extern "C" int taco_step_inc(int* global_step, hipStream_t stream) {
-    hipLaunchKernelGGL(step_inc_k, dim3(1), dim3(64), 0, stream, global_step);
+extern "C" int taco_step_inc(int* global_step, const int* err, hipStream_t stream) {
+    if (!global_step) return TACO_EINVAL;
+    hipLaunchKernelGGL(step_inc_k, dim3(1), dim3(64), 0, stream, global_step, err);
     TACO_RETURN_LAST();
 }
 

@@ -29,6 +29,28 @@ __device__ __forceinline__ unsigned xcc_id() {
 }
 #define TACO_XCD_TAG 0x58434431u     // 'XCD1': epoch of the placement granules (step epochs start at 1 and stay far below)
 #define TACO_XCD_SPIN (1 << 22)
+// Workgroup-wide form: lane i < cw polls member i's placement granule; the verdict is broadcast through the LDS int *flag_l.
+// Contains two workgroup barriers: every thread of the workgroup must call it.  allow = 0 skips the exchange (agent scope).
+__device__ __forceinline__ bool cluster_shares_xcd(u64* slots, int w, int cw, int* err, int* flag_l, int tid, int allow) {
+    if (tid == 0) *flag_l = allow ? 1 : 0;
+    __syncthreads();
+    if (allow && tid < cw) {
+        const unsigned mine = xcc_id();
+        if (tid == 0) __hip_atomic_store(slots + w, ((u64)TACO_XCD_TAG << 32) | (u64)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 x;
+        int spins = 0;
+        bool ok = true;
+        for (;;) {
+            x = __hip_atomic_load(slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(x >> 32) == TACO_XCD_TAG) break;
+            if (++spins > TACO_XCD_SPIN) { if (err) atomicExch(err, 1); ok = false; break; }
+        }
+        if (!ok || (unsigned)x != mine) *flag_l = 0;
+    }
+    __syncthreads();
+    return *flag_l != 0;
+}
+
 // One lane per workgroup calls this (then broadcasts the result through LDS).  slots: >= cw zeroed granules of this cluster.
 __device__ __forceinline__ bool cluster_on_one_xcd(u64* slots, int w, int cw, int* err) {
     const unsigned mine = xcc_id();

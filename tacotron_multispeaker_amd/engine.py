@@ -28,6 +28,38 @@ _AP = ['W1C', 'F1', 'W2', 'B2', 'WX', 'WHG', 'WHC', 'BG', 'WQ', 'V', 'KEYS', 'ME
 AP = {n: i for i, n in enumerate(_AP)}
 
 
+_DEVICE_LOCKS = {}
+
+
+def _claim_device(dev):
+    """The persistent cluster kernels need ALL their workgroups co-resident (they spin on each other's granules), which holds
+    only while this process has the GPU to itself: kernels of a second process can keep CUs busy so that a partially
+    dispatched cluster spins to its bound (err word) -- or, inside a HIP-graph replay, until the queue watchdog aborts the
+    process (round-1 record gpurun_out/time14b.log: two copies of one script started 2 s apart on one GPU; the copy that
+    was capturing / replaying the full-step graph dumped core, the same script alone never did).  One process per GPU is the
+    deployment model anyway (torch.distributed rank = GPU); this advisory lock turns an accidental second process into a
+    clear error instead.  TACO_ALLOW_SHARED_GPU=1 skips it."""
+    if os.environ.get('TACO_ALLOW_SHARED_GPU', '0') == '1':
+        return
+    import fcntl
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    pr = torch.cuda.get_device_properties(idx)
+    ident = getattr(pr, 'uuid', None) or '%s-%s-%s' % (getattr(pr, 'pci_domain_id', 0), getattr(pr, 'pci_bus_id', idx),
+                                                          getattr(pr, 'pci_device_id', 0))
+    key = str(ident)
+    if key in _DEVICE_LOCKS:
+        return
+    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'taco_hip_gpu_%s.lock' % key.replace('/', '_'))
+    f = open(path, 'a+')
+    try:
+        fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+    except OSError:
+        f.close()
+        raise RuntimeError('another process already runs the tacotron_multispeaker_amd engine on GPU %s (%s): the persistent '
+                           'cluster kernels need the device to themselves; use one process per GPU' % (idx, path))
+    _DEVICE_LOCKS[key] = f
+
+
 class Engine:
     def __init__(self, vocab=7352, embed_text=256, embed_id=64, id_num=0, r=5, num_mels=80, num_freq=1025,
                  sample_rate=20000, init_lr=0.002, decay_lr=True, beta1=0.9, beta2=0.999, tf_sparse_norm=True,
@@ -36,6 +68,7 @@ class Engine:
             raise RuntimeError('tacotron_multispeaker_amd.Engine needs an MI355X (HIP) device; there is no CPU path')
         lib.load()
         self.dev = torch.device(device)
+        _claim_device(self.dev)
         self.L = ParamLayout(vocab, embed_text, embed_id, id_num, r, num_mels, num_freq)
         L = self.L
         self.r, self.nm, self.nf = r, num_mels, num_freq
@@ -69,7 +102,10 @@ class Engine:
         self.last_chunk_frac = float(os.environ.get('TACO_LAST_CHUNK', '0.5'))     # last chunk length / (S / chunks)
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
-        self.world = 1
+        self.world = 1                 # data-parallel replicas (set by train.py / bench.py after init_process_group)
+        self.comm_stream = torch.cuda.Stream(device=self.dev)    # bucket all-reduces are ordered behind this stream
+        self._exchange = None
+        self.exposed_events = None     # bench: list of (event, event) pairs around the wait for the gradient exchange
         self.load_named(named_params if named_params is not None else init_named(L, seed))
 
     # ---- parameters ---------------------------------------------------------------------------------------
@@ -120,14 +156,34 @@ class Engine:
     def st(self):
         return torch.cuda.current_stream().cuda_stream
 
+    # ---- optional in-step kernel timing (bench.py): HIP events around every launch of a kernel family, recorded on the stream
+    # the kernel is launched on; ktime = None (default) costs nothing
+    ktime = None
+
+    def _timed(self, family, flops, fn):
+        if self.ktime is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.ktime.append((family, float(flops), e0, e1))
+
     # ---- op helpers ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _gemm_flops(M, Cin, Cout, kw, bank):
+        taps = bank * (bank + 1) // 2 if bank else kw
+        return 2.0 * M * Cin * (128 if bank else Cout) * taps
+
     def gemm(self, X, W, bias, Y, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, ldw=None, ldy=None, act=0, acc=0):
-        lib.taco_conv_gemm_fwd(X, W, bias, Y, M, T or M, Cin, Cout, kw, bank,
-                               ldx or X.stride(-2), ldw or Cout, ldy or Y.stride(-2), act, acc, self.st)
+        self._timed('fwd GEMM (conv_gemm_nn2)', self._gemm_flops(M, Cin, Cout, kw, bank),
+                    lambda: lib.taco_conv_gemm_fwd(X, W, bias, Y, M, T or M, Cin, Cout, kw, bank,
+                                                   ldx or X.stride(-2), ldw or Cout, ldy or Y.stride(-2), act, acc, self.st))
 
     def gemm_dx(self, dY, W, dX, M, Cin, Cout, T=None, kw=1, bank=0, lddy=None, ldw=None, lddx=None, acc=0):
-        lib.taco_conv_gemm_bwd_data(dY, W, dX, M, T or M, Cin, Cout, kw, bank,
-                                    lddy or dY.stride(-2), ldw or Cout, lddx or dX.stride(-2), acc, self.st)
+        self._timed('dX GEMM (conv_gemm_nt2)', self._gemm_flops(M, Cin, Cout, kw, bank),
+                    lambda: lib.taco_conv_gemm_bwd_data(dY, W, dX, M, T or M, Cin, Cout, kw, bank,
+                                                        lddy or dY.stride(-2), ldw or Cout, lddx or dX.stride(-2), acc, self.st))
 
     # Weight / bias gradients only feed the flat gradient buffer, so during backward they are enqueued on a SIDE
     # stream (forked from / joined to the main stream with events; captured as a parallel branch of the HIP graph)
@@ -150,17 +206,46 @@ class Engine:
         # independent weight-gradient launches (distinct outputs, atomic accumulation) are dealt round-robin over the side
         # streams, so that the many short ones at the end of backward do not serialise behind each other
         for fn in self._deferred:
+            if isinstance(fn, tuple):      # ('bucket', go): every producer of a gradient bucket is now enqueued
+                fn[1]()
+                continue
             with torch.cuda.stream(self.side_streams[self._side_rr % len(self.side_streams)]):
                 fn()
             self._side_rr += 1
         self._deferred = []
 
+    # ---- data-parallel exchange overlapped with backward (tacotron_multispeaker_amd/dp.py) --------------
+    def _bucket_ready(self, k):
+        """Called by backward() where the LAST producer of gradient bucket k (dp.bucket_ranges order) has just been created.
+        Main-stream producers are captured by an event recorded here; side-stream producers (deferred weight-gradient GEMMs)
+        by a marker in the deferred queue: when flush_side() reaches it they are all enqueued, the communication stream is
+        made to wait for them and the bucket's all-reduce is launched behind it -- while the BPTT of the earlier layers is
+        still running.  Program order is identical on every rank, so the collectives are issued in the same order."""
+        if self.world <= 1 or self._exchange is None or k >= len(self._exchange.ranges):
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def go():
+            cs = self.comm_stream
+            cs.wait_event(ev)
+            for ss in self.side_streams:
+                cs.wait_stream(ss)
+            with torch.cuda.stream(cs):
+                self._exchange.launch(k)
+        if self._side_active:
+            self._deferred.append(('bucket', go))
+        else:
+            go()
+
     def gemm_dw(self, X, dY, dW, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, lddy=None, ldw=None):
-        self._side(lambda: lib.taco_conv_gemm_bwd_weight(X, dY, dW, M, T or M, Cin, Cout, kw, bank,
-                                                         ldx or X.stride(-2), lddy or dY.stride(-2), ldw or Cout, self.st))
+        self._side(lambda: self._timed('dW GEMM (conv_gemm_tn2)', self._gemm_flops(M, Cin, Cout, kw, bank),
+                                       lambda: lib.taco_conv_gemm_bwd_weight(X, dY, dW, M, T or M, Cin, Cout, kw, bank,
+                                                                             ldx or X.stride(-2), lddy or dY.stride(-2), ldw or Cout, self.st)))
 
     def gemm_dw_shift(self, X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift=-1):
-        self._side(lambda: lib.taco_gemm_tn_shift(X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift, self.st))
+        self._side(lambda: self._timed('dW GEMM (conv_gemm_tn2)', 2.0 * M * K * N,
+                                       lambda: lib.taco_gemm_tn_shift(X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift, self.st)))
 
     def colsum(self, x, out, M, C, ldx=None):
         self._side(lambda: lib.taco_col_sum(x, ldx or x.stride(-2), out, M, C, self.st))
@@ -228,11 +313,12 @@ class Engine:
         self.gemm(hw, self.P(sc + '/bigru/wx'), self.P(sc + '/bigru/bias'), XP, M, 128, 768)
         OUT = self.buf(sc + '/out', M, 256)
         RUC = self.buf(sc + '/ruc', 2, N, T, 384)
-        lib.taco_gru128_seq_fwd(XP, 768, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
-                                self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC, N, T, 2, st)
+        self._timed('biGRU(128) fwd (gru128_seq_fwd_k)', 2.0 * 2 * M * 128 * 384,
+                    lambda: lib.taco_gru128_seq_fwd(XP, 768, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
+                                                    self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC, N, T, 2, st))
         return OUT
 
-    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx, eager=False):
+    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx, eager=False, after_proj2=None):
         """dOUT [M,256] gradient wrt the CBHG output; writes the gradient wrt the CBHG input x into dx [M,cin].
         eager: release the deferred weight-gradient launches to the side stream after every block (encoder: nothing
         latency-bound follows that they could disturb, and held back they would run as a serial tail after the main stream)."""
@@ -242,9 +328,10 @@ class Engine:
         OUT, RUC = b[sc + '/out'], b[sc + '/ruc']
         dXP = self.buf(sc + '/dxp', M, 768)
         HP, RH = self.buf(sc + '/hp', 2, M, 128), self.buf(sc + '/rh', 2, M, 128)
-        lib.taco_gru128_seq_bwd(dOUT, 256, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
-                                self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC,
-                                dXP, 768, HP, RH, N, T, 2, st)
+        self._timed('biGRU(128) bwd (gru128_seq_bwd_k)', 2.0 * 2 * M * 128 * 384,
+                    lambda: lib.taco_gru128_seq_bwd(dOUT, 256, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
+                                                    self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC,
+                                                    dXP, 768, HP, RH, N, T, 2, st))
         self.flush_side()
         hw4 = b[sc + '/hw4']
         self.gemm_dw(hw4, dXP, self.G(sc + '/bigru/wx'), M, 128, 768)
@@ -275,6 +362,8 @@ class Engine:
         self.gemm_dw(b[sc + '/y1'], dC2, self.G(sc + '/proj_2/kernel'), M, proj[0], proj[1], T=T, kw=3)
         dY1 = self.buf(sc + '/dy1', M, proj[0])
         self.gemm_dx(dC2, self.P(sc + '/proj_2/kernel'), dY1, M, proj[0], proj[1], T=T, kw=3)
+        if after_proj2 is not None:
+            after_proj2()              # gradients of the biGRU, the highways and proj_2 are all created: bucket boundary
         flush()
         dC1 = self.buf(sc + '/dc1', M, proj[0])
         self.bn_bwd(sc + '/proj_1', b[sc + '/c1'], dY1, dC1, M, proj[0], T, 0, 1)
@@ -331,12 +420,15 @@ class Engine:
         # Chunk-pipelined decoder: attention recurrence on the current stream, GRU1 / GRU2 on two more streams; chunk c
         # of GRU1 (its hoisted projections first) starts as soon as the attention kernel has finished chunk c.
         chunks = self._chunks(N, S, Ti)
+        if len(chunks) > 1:
+            self._check_residency(N, Ti)
         cur = torch.cuda.current_stream()
         sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
         Wp, bp = self.P('concat_projection/kernel'), self.P('concat_projection/bias')
         for (s0, s1) in chunks:
             for nb, tab in self._attn_ptrs:
-                lib.taco_attn_rnn_fwd(tab, self._dims(nb, S, Ti, s0, s1), self.st)
+                self._timed('attention recurrence fwd (attn_cluster_fwd_k)', self._attn_flops(nb, Ti, s1 - s0),
+                            lambda: lib.taco_attn_rnn_fwd(tab, self._dims(nb, S, Ti, s0, s1), self.st))
             ev = torch.cuda.Event(); ev.record(cur)
             sb.wait_event(ev)
             with torch.cuda.stream(sb):
@@ -365,6 +457,18 @@ class Engine:
         self.encoder_outputs = ENC.view(N, Ti, 256)
         return MEL, LIN, self.alignments
 
+    def _check_residency(self, N, Ti):
+        """Worst case of persistent workgroups in flight at once: the chunk pipeline runs one attention launch, one GRU1 and
+        one GRU2 launch concurrently on three streams (launches of one kind serialise on their stream): 8*ceil(nb/2) +
+        2 * 4*ceil(min(N,128)/2) workgroups of 512 threads (nb = min(N, 64) attention rows per launch).  All of them spin on
+        peers, so all must be resident: a CU holds two such workgroups (launch bounds (512, 2): 256 VGPRs per lane each),
+        i.e. 512 on the chip; C2 uses 128 + 64 + 64, the largest configuration allowed here (N >= 128) 256 + 128 + 128.
+        Side-stream GEMM workgroups never spin, so they can delay a cluster workgroup's dispatch but not deadlock it."""
+        attn = 8 * ((min(N, self.ATTN_ROWS) + 1) // 2)
+        gru = 4 * ((min(N, self.GRU256_ROWS) + 1) // 2)
+        if attn > 256 or gru > 256 or attn + 2 * gru > 512:
+            raise RuntimeError('persistent cluster kernels would not be co-resident: %d + 2*%d workgroups' % (attn, gru))
+
     def _chunks(self, N, S, Ti, k=None):
         """Step ranges for the chunk-pipelined decoder (needs the cluster path); [(0, S)] = no pipelining."""
         k = k or self.pipe_chunks
@@ -376,6 +480,12 @@ class Engine:
         step = (S - last + k - 2) // (k - 1)
         bounds = [min(S - last, i * step) for i in range(k)] + [S]
         return [(bounds[i], bounds[i + 1]) for i in range(k) if bounds[i + 1] > bounds[i]]
+
+    @staticmethod
+    def _attn_flops(N, Ti, steps):
+        """forward FLOPs of the attention recurrence per launch (prenet context part + dense_2, GRU(256) on a
+        128-wide input, query projection, 5*Ti*256 for the score / softmax / context tile)"""
+        return steps * (2.0 * N * (256 * 256 + 256 * 128) + 2.0 * N * 384 * 768 + 2.0 * N * 256 * 256 + 5.0 * N * Ti * 256)
 
     def _dims(self, N, S, Ti, s0, s1):
         return (ctypes.c_int * 5)(N, S, Ti, s0, s1)
@@ -389,15 +499,17 @@ class Engine:
         for n0 in range(0, N, self.GRU256_ROWS):
             n1 = min(N, n0 + self.GRU256_ROWS)
             v = lambda a, w: a.view(N, S * w)[n0:n1]
-            lib.taco_gru256_seq_fwd(v(xp, 768), whg, whc, v(res, 256), v(t[0], 256), v(t[1], 256), v(t[2], 256), v(t[3], 256),
-                                    v(t[4], 256), v(d, 256), xchg, self.err, n1 - n0, S, s0, s1, self.st)
+            self._timed('decoder GRU(256) fwd (gru256_cluster_fwd_k)', (s1 - s0) * 2.0 * (n1 - n0) * 256 * 768,
+                        lambda: lib.taco_gru256_seq_fwd(v(xp, 768), whg, whc, v(res, 256), v(t[0], 256), v(t[1], 256), v(t[2], 256),
+                                                        v(t[3], 256), v(t[4], 256), v(d, 256), xchg, self.err, n1 - n0, S, s0, s1, self.st))
 
     def gru256_bwd(self, dout, whg, whc, r, u, c, h, dxp, carry, xchg, N, S, s0, s1):
         for n0 in range(0, N, self.GRU256_ROWS):
             n1 = min(N, n0 + self.GRU256_ROWS)
             v = lambda a, w: a.view(N, S * w)[n0:n1]
-            lib.taco_gru256_seq_bwd(v(dout, 256), whg, whc, v(r, 256), v(u, 256), v(c, 256), v(h, 256), v(dxp, 768),
-                                    carry.view(N, 256)[n0:n1], xchg, self.err, n1 - n0, S, s0, s1, self.st)
+            self._timed('decoder GRU(256) bwd (gru256_cluster_bwd_k)', (s1 - s0) * 2.0 * (n1 - n0) * 256 * 768,
+                        lambda: lib.taco_gru256_seq_bwd(v(dout, 256), whg, whc, v(r, 256), v(u, 256), v(c, 256), v(h, 256), v(dxp, 768),
+                                                        carry.view(N, 256)[n0:n1], xchg, self.err, n1 - n0, S, s0, s1, self.st))
 
     def dense_rows(self, x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, ldy):
         lib.taco_dense_rows_fwd(x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, cout, ldy, 0, 0, self.st)
@@ -410,12 +522,14 @@ class Engine:
         return max(dll.taco_attn_cluster_xchg_slots(N, Ti), dll.taco_attn_cluster_bwd_xchg_slots(N, Ti))
 
     _IP = ['W1', 'B1', 'W2', 'B2', 'WX', 'WHG', 'WHC', 'BG', 'WQ', 'V', 'KEYS', 'MEM', 'ZEROS', 'WP', 'BP', 'G1WX', 'G1B', 'G1WHG',
-           'G1WHC', 'G2WX', 'G2B', 'G2WHG', 'G2WHC', 'WO', 'BO', 'HC', 'ALIGN', 'OUT', 'H1', 'H2', 'TMP']
+           'G1WHC', 'G2WX', 'G2B', 'G2WHG', 'G2WHC', 'WO', 'BO', 'HC', 'ALIGN', 'OUT', 'H1', 'H2', 'TMP', 'STOP']
+    INFER_POLL = 100      # decoder steps enqueued between two reads of the device-side stop count
 
     def infer(self, inputs, input_lengths, identities=None, steps=None, max_iters=2000):
         """Free-running synthesis (reference models/tacotron.py:18-104 with linear_targets=None, models/helpers.py:7-38):
-        batch norm in inference mode, the last predicted frame fed back, `steps` decoder steps (default max_iters: the
-        reference's exact-zero stop token never fires in practice).  Returns (mel [N,S*r,80], linear, alignments [N,Ti,S])."""
+        batch norm in inference mode, the last predicted frame fed back, at most `steps` (default max_iters) decoder steps;
+        decoding ends early once every row has produced an exactly-zero r-frame output (the reference's stop token, kept on
+        the device and polled every INFER_POLL steps).  Returns (mel [N,S*r,80], linear, alignments [N,Ti,S]), S = steps run."""
         L, st = self.L, self.st
         N, Ti = inputs.shape
         S = int(steps if steps is not None else max_iters)
@@ -442,15 +556,29 @@ class Engine:
              'G2WX': P('decoder_gru_2/wx'), 'G2B': P('decoder_gru_2/bias'), 'G2WHG': P('decoder_gru_2/whg'), 'G2WHC': P('decoder_gru_2/whc'),
              'WO': P('output_projection/kernel'), 'BO': P('output_projection/bias'),
              'HC': self.buf('i_HC', N * S, 512), 'ALIGN': self.buf('i_ALIGN', N * S, Ti), 'OUT': self.buf('i_mel', N, S * r, nm),
-             'H1': self.buf('i_H1', 2, N, 256), 'H2': self.buf('i_H2', 2, N, 256), 'TMP': self.buf('i_TMP', 10, N, 256)}
+             'H1': self.buf('i_H1', 2, N, 256), 'H2': self.buf('i_H2', 2, N, 256), 'TMP': self.buf('i_TMP', 10, N, 256),
+             'STOP': self.buf('i_STOP', 1 + N, dtype=torch.int32)}
+        t['STOP'].zero_(); t['STOP'][0:1].fill_(S)
         arr = (ctypes.c_void_p * len(self._IP))(*[t[n].data_ptr() for n in self._IP])
-        lib.taco_decoder_infer(arr, (ctypes.c_int * 5)(N, S, Ti, r, nm), st)
+        keep = S
+        for s0 in range(0, S, self.INFER_POLL):
+            s1 = min(S, s0 + self.INFER_POLL)
+            lib.taco_decoder_infer(arr, (ctypes.c_int * 7)(N, S, Ti, r, nm, s0, s1), st)
+            keep = int(t['STOP'][0].item())            # synchronises: the post-net needs the final length anyway
+            if keep < S:
+                break
         MEL = t['OUT']
+        ALIGN = t['ALIGN'].view(N, S, Ti)
+        if keep < S:                                    # every row hit the stop token: keep steps [0, keep)
+            MEL = self.buf('i_mel_cut', N, keep * r, nm)
+            MEL.copy_(t['OUT'].view(N, S, r * nm)[:, :keep].reshape(N, keep * r, nm))
+            ALIGN = ALIGN[:, :keep]
+            S = keep
         POST = self.cbhg_fwd('post_cbhg', MEL.view(N * S * r, nm), N, S * r, nm, 8, (256, nm), None, False)
         LIN = self.buf('i_lin', N, S * r, self.nf)
         self.gemm(POST, self.P('linear/kernel'), self.P('linear/bias'), LIN, N * S * r, 256, self.nf, ldw=L.ld_lin, ldy=self.nf)
         self.mel_outputs, self.linear_outputs = MEL, LIN
-        self.alignments = t['ALIGN'].view(N, S, Ti).transpose(1, 2)
+        self.alignments = ALIGN.transpose(1, 2)
         self.encoder_outputs = ENC.view(N, Ti, 256)
         return MEL, LIN, self.alignments
 
@@ -541,6 +669,13 @@ class Engine:
         E = L.Et + L.Es
         self.grads.zero_()
         self._side_active = self.overlap_wgrad
+        if self.world > 1:
+            from . import dp
+            if self._exchange is None:
+                self._exchange = dp.BucketExchange(self.grads, dp.bucket_ranges(self.L, int(os.environ.get('TACO_DP_BUCKETS', '4'))),
+                                                   self.world)
+            self._exchange.begin()
+        nb = len(self._exchange.ranges) if (self.world > 1 and self._exchange is not None) else 0
         dLIN, POST = b['dlin'], b['post_cbhg/out']
         # linear layer (tacotron.py:101)
         self.gemm_dw(POST, dLIN, self.G('linear/kernel'), Mp, 256, self.nf, ldw=L.ld_lin)
@@ -549,6 +684,8 @@ class Engine:
         self.gemm_dx(dLIN, self.P('linear/kernel'), dPOST, Mp, 256, L.ld_lin, ldw=L.ld_lin)
         dMELp = self.buf('dmel_post', Mp, nm)
         self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, dMELp)
+        if nb >= 2:
+            self._bucket_ready(0)                       # post-net + linear
         dOUT = self.buf('dout', Ms, nm * r)
         lib.taco_add(dMELp, b['dmel_loss'], dOUT, Mp * nm, 0, st)
         # output projection
@@ -585,7 +722,8 @@ class Engine:
                 self.dense_rows_dx(dxp[1], self.P('decoder_gru_1/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dY = dD1 + dxp1.Wx1^T
                 self.dense_rows_dx(dD, Wp, dHC, N, S, s0, s1, 512, 256, 256, 512, 0)                               # d[h|ctx] = dY.Wp^T
                 for nb, tab in self._attn_ptrs:
-                    lib.taco_attn_rnn_bwd(tab, self._dims(nb, S, Ti, s0, s1), self.st)
+                    self._timed('attention recurrence bwd (attn_cluster_bwd_k)', 2 * self._attn_flops(nb, Ti, s1 - s0),
+                                lambda: lib.taco_attn_rnn_bwd(tab, self._dims(nb, S, Ti, s0, s1), self.st))
             if ci == flush_at:
                 # post-net weight gradients fill the CUs the recurrences leave idle; released once the GRU BPTT chunks
                 # (which crowd the first attention chunks) are mostly done
@@ -620,8 +758,11 @@ class Engine:
         ENC, dKEYS, dENC = b['encoder_cbhg/out'], b['dKEYS'], b['dMEM']
         self.gemm_dw(ENC, dKEYS, self.G('attention/memory_layer/kernel'), Me, 256, 256)
         self.gemm_dx(dKEYS, self.P('attention/memory_layer/kernel'), dENC, Me, 256, 256, acc=1)
+        if nb >= 4:
+            self._bucket_ready(1)                       # attention + decoder
         dA2 = self.buf('d_enc_p2', Me, 128)
-        self.cbhg_bwd('encoder_cbhg', b['enc_p2'], dENC, N, Ti, 128, 16, (128, 128), self.input_lengths, dA2, eager=True)
+        self.cbhg_bwd('encoder_cbhg', b['enc_p2'], dENC, N, Ti, 128, 16, (128, 128), self.input_lengths, dA2, eager=True,
+                      after_proj2=(lambda: self._bucket_ready(2)) if nb >= 4 else None)
         # encoder prenet + embeddings
         lib.taco_relu_bwd(b['enc_p2'], dA2, dA2, Me * 128, st)
         dA1 = self.buf('d_enc_p1', Me, 256)
@@ -634,6 +775,8 @@ class Engine:
                                    self.G('embedding_id') if L.Es else None,
                                    self.gnorm2 if (self.tf_sparse_norm and self.world == 1) else None,
                                    N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
+        if nb:
+            self._bucket_ready(nb - 1)                  # embeddings, encoder prenet, conv bank, proj_1: the tail of backward
         if self._side_active:
             self.flush_side()
             for ss in self.side_streams:
@@ -648,23 +791,29 @@ class Engine:
             lib.taco_sumsq(self.grads[L.dense_start:], L.total - L.dense_start, self.gnorm2, st)
         else:
             lib.taco_sumsq(self.grads, L.total, self.gnorm2, st)
+        # the three launches skip themselves on the device when a cluster hand-off of this step timed out (self.err != 0):
+        # garbage gradients never reach the weights; the host raises at its next read-back (check_errors)
+        # under data parallelism self.grads holds the SUM over replicas: the 1/world of the average is applied inside the
+        # kernel (norm and update), not in a pass of its own
         lib.taco_adam_step(self.params, self.grads, self.m, self.v, L.total, self.gnorm2, self.global_step, self.init_lr,
-                           1 if self.decay_lr else 0, self.beta1, self.beta2, 1e-8, 1.0, self.info, st)
+                           1 if self.decay_lr else 0, self.beta1, self.beta2, 1e-8, 1.0, 1.0 / max(self.world, 1), self.info,
+                           self.err, st)
         if L.bn_total:
-            lib.taco_bn_ema(self.bn, self.bnbatch, L.bn_total, BN_MOMENTUM, st)     # UPDATE_OPS (tacotron.py:193)
-        lib.taco_step_inc(self.global_step, st)
+            lib.taco_bn_ema(self.bn, self.bnbatch, L.bn_total, BN_MOMENTUM, self.global_step, self.err, st)   # UPDATE_OPS (tacotron.py:193) + step counter
+        else:
+            lib.taco_step_inc(self.global_step, self.err, st)
 
     def allreduce_grads(self):
-        """Data parallel exchange step (net-new): RCCL all-reduce(sum)/world of the flat gradient,
-        in contiguous backward-order buckets (tacotron_multispeaker_amd/dp.py)."""
-        if self.world > 1:
-            from . import dp
-            if getattr(self, '_buckets', None) is None:
-                # the exchange runs after backward has finished (no overlap yet), so one 35 MB message beats four
-                # smaller ones on the ring; TACO_DP_BUCKETS=4 restores the backward-order buckets
-                self._buckets = dp.bucket_ranges(self.L, int(os.environ.get('TACO_DP_BUCKETS', '1')))
-            dp.allreduce_average(self.grads, self.world, self._buckets,
-                                 scale_fn=lambda flat, s: lib.taco_scale(flat, flat.numel(), s, self.st))
+        """Data parallel exchange step (net-new): completes the bucketed RCCL all-reduce(sum) of the flat
+        gradient that backward() launched bucket by bucket (tacotron_multispeaker_amd/dp.py); the current stream waits for
+        the communication, the host does not.  The 1/world factor is applied by the optimizer kernels."""
+        if self.world > 1 and self._exchange is not None:
+            if self.exposed_events is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            self._exchange.finish()
+            if self.exposed_events is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                self.exposed_events.append((e0, e1))
 
     def train_step(self, inputs, input_lengths, mel_targets, linear_targets, identities=None):
         self.forward(inputs, input_lengths, mel_targets, identities, training=True)

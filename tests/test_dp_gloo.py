@@ -1,5 +1,6 @@
-"""Data-parallel exchange step on CPU (gloo, world_size 2): the bucketed all-reduce of the flat gradient
-buffer used by the engine averages the replicas' gradients and leaves both ranks bit-identical."""
+"""Data-parallel exchange step on CPU (gloo, world_size 2): the bucketed all-reduce of the flat gradient buffer, launched
+bucket by bucket out of band as the engine does during backward (tacotron_multispeaker_amd/dp.py BucketExchange), sums the
+replicas' gradients and leaves both ranks bit-identical."""
 import os
 import socket
 import sys
@@ -41,14 +42,35 @@ def _worker(rank, world, port, q):
     buckets = dp.bucket_ranges(L, n_buckets=4)
     assert buckets[0][1] == L.total and buckets[-1][0] == 0           # backward order: post-net/linear first
     assert all(a[0] == b_[1] for a, b_ in zip(buckets[:-1], buckets[1:]))
-    dp.allreduce_average(flat, world, buckets=buckets)
+    assert buckets[1][0] == L.entries['attention/memory_layer/kernel'].offset       # attention + decoder
+    assert buckets[2][0] == L.entries['encoder_cbhg/proj_2/kernel'].offset          # encoder proj_2 / highways / biGRU
+    # Out-of-band exchange as the engine drives it: the gradient buffer starts at zero (backward zero-fills it), each bucket
+    # is all-reduced the moment it has been produced while the later ones do not exist yet; three are launched out of
+    # band, finish() launches the tail and waits.
+    flat.zero_()
+    ex = dp.BucketExchange(flat, buckets, world)
+    ex.begin()
+    for i in range(3):
+        b0, b1 = buckets[i]
+        flat[b0:b1] = local[b0:b1]                # "backward" produces bucket i ...
+        ex.launch(i)                              # ... and its exchange starts while bucket i+1 is still being computed
+    b0, b1 = buckets[3]
+    flat[b0:b1] = local[b0:b1]
+    ex.finish()
+    assert ex.order == [0, 1, 2, 3]
+    summed = flat.clone()
+    flat.mul_(1.0 / world)                        # the engine applies this factor inside the optimizer kernels
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     expect = sum(gathered) / world
-    ok_avg = bool(torch.allclose(flat, expect, rtol=0, atol=1e-7))
+    ok_avg = bool(torch.allclose(flat, expect, rtol=0, atol=1e-7)) and bool(torch.equal(summed, gathered[0] + gathered[1]))
     allf = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(allf, flat)
     ok_same = all(torch.equal(allf[0], t) for t in allf)
+    # the blocking one-message form gives the same bits
+    again = local.clone()
+    dp.allreduce_average(again, world, buckets=dp.bucket_ranges(L, n_buckets=1))
+    ok_same = ok_same and bool(torch.equal(again, flat))
     q.put((rank, ok_avg, ok_same, float(flat.abs().sum())))
     dist.destroy_process_group()
 

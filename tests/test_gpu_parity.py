@@ -244,23 +244,20 @@ def test_alignment_regularisers_match_oracle(cfg, monkeypatch):
     b = onp.synth_batch(N, Ti, To, r, seed=37, id_num=idn)
     pad = b['inputs'] == 0
     b['inputs'][pad] = np.random.RandomState(9).randint(2, 7352, size=int(pad.sum()))     # tie-free max-pool (see above)
-    ts = ot.TrainState(P, torch.float64, id_num=idn, r=r, regularity=reg)
-    last = ts.forward_backward(b)
+    from decisions import oracle_step_aligned
     plain = ot.TrainState(P, torch.float64, id_num=idn, r=r).forward_backward(b)
-    eng = Engine(id_num=idn, r=r, named_params=P)
-    eng.set_regularity(**reg)
-    i, l, m, lin, ids = dev_batch(b, eng.dev)
-    eng.forward(i, l, m, ids)
-    eng.loss(lin)
-    eng.backward()
-    torch.cuda.synchronize()
-    assert int(eng.err.item()) == 0
-    loss = eng.loss_values()[0]
+
+    def run():
+        o = run_engine_step(P, b, r, idn, apply=False, regularity=reg)
+        return o['eng'], o
+    ts, last, o, flips = oracle_step_aligned(P, b, r, idn, run, regularity=reg)       # ReLU / max-pool decisions aligned
+    eng = o['eng']
+    loss = o['loss'][0]
     a_np = last['out']['alignments'].detach().numpy()
     assert abs(onp.alignment_regularity(a_np, **reg) - last['loss_regularity']) < 1e-9 * abs(last['loss_regularity'])
     assert abs(eng.loss_regularity - last['loss_regularity']) < 1e-4 * abs(last['loss_regularity'])
     assert abs(loss - last['loss']) < 1e-5 * last['loss']
-    grads = eng.export_named('grads')
+    grads = o['grads']
     gmax = max(float(v.norm()) for v in last['grads'].values())
     moved = 0
     for k, v in last['grads'].items():
@@ -459,6 +456,210 @@ def test_free_running_inference_matches_oracle(cfg):
     assert rel(mel.cpu().numpy(), ref['mel_outputs']) < TOL
     assert rel(lin.cpu().numpy(), ref['linear_outputs']) < TOL
     assert rel(al.cpu().numpy(), ref['alignments']) < TOL
+
+
+def test_free_running_inference_stop_token():
+    """models/helpers.py:32-38: a row is finished once a whole r-frame output is exactly zero; decoding ends when all rows
+    are.  A zero output projection makes every output exactly 0 at step 0, so both the oracle and the HIP path stop after ONE
+    step although max_iters = 7; with a non-zero bias nothing stops and all 7 steps run."""
+    from oracle import tacotron_np as onp
+    from tacotron_multispeaker_amd.engine import Engine
+    N, Ti, r = 3, 11, 5
+    P = onp.init_params(seed=9, r=r)
+    b = onp.synth_batch(N, Ti, 10 * r, r, seed=5)
+    P['output_projection/kernel'] = np.zeros_like(P['output_projection/kernel'])
+    P['output_projection/bias'] = np.zeros_like(P['output_projection/bias'])
+    ref = onp.forward_infer(P, b['inputs'], b['input_lengths'], None, 0, r, max_iters=7)
+    assert ref['mel_outputs'].shape == (N, r, 80)
+    eng = Engine(r=r, named_params=P)
+    i, l, _, _, _ = dev_batch(b, eng.dev)
+    mel, lin, al = eng.infer(i, l, None, max_iters=7)
+    torch.cuda.synchronize()
+    assert mel.shape == (N, r, 80) and lin.shape == (N, r, 1025) and al.shape == (N, Ti, 1)
+    assert float(mel.abs().max()) == 0.0
+    assert rel(lin.cpu().numpy(), ref['linear_outputs']) < TOL
+    assert rel(al.cpu().numpy(), ref['alignments']) < TOL
+    P['output_projection/bias'] = P['output_projection/bias'] + 0.25
+    eng2 = Engine(r=r, named_params=P)
+    mel2, _, al2 = eng2.infer(i, l, None, max_iters=7)
+    ref2 = onp.forward_infer(P, b['inputs'], b['input_lengths'], None, 0, r, max_iters=7)
+    assert mel2.shape == (N, 7 * r, 80) == ref2['mel_outputs'].shape and al2.shape == (N, Ti, 7)
+    assert rel(mel2.cpu().numpy(), ref2['mel_outputs']) < TOL
+
+
+def test_checkpoint_resume_reproduces_the_next_step():
+    """SURVEY.md 8(f) row f2 (reference train.py:125-129): state_dict at step 5 -> a NEW model -> load_state_dict restores
+    parameters, Adam slots, BN moving statistics and global_step bit for bit, and step 6 of the resumed run gives the loss of
+    the uninterrupted run.  (Not bit for bit: weight gradients and BN sums accumulate with fp32 / fp64 atomics whose order
+    varies from launch to launch; two identical uninterrupted runs differ by the same ~1e-6.)  A checkpoint of another
+    layout (outputs_per_step) is rejected."""
+    import importlib
+    import hparams as H
+    importlib.reload(H)
+    from models import create_model
+    from models.tacotron import GlobalStep
+    from oracle import tacotron_np as onp
+    H.hparams.parse('outputs_per_step=5,decay_learning_rate=false,initial_learning_rate=0.001')
+    bs = [onp.synth_batch(3, 14, 30, 5, seed=60 + i) for i in range(6)]
+
+    def make(seed):
+        m = create_model('tacotron', H.hparams)
+        m.initialize(bs[0]['inputs'], bs[0]['input_lengths'], bs[0]['mel_targets'], bs[0]['linear_targets'], seed=seed)
+        m.add_loss(); m.add_optimizer(GlobalStep())
+        return m
+
+    def step(m, b):
+        m._set_batch(b['inputs'], b['input_lengths'], b['mel_targets'], b['linear_targets'], None)
+        return m.run_step()
+
+    a = make(0)
+    for i in range(5):
+        out = step(a, bs[i])
+    assert out[0] == 5
+    sd = a.state_dict()
+    torch.save(sd, '/tmp/_taco_ckpt_test.pt')
+    loss6 = step(a, bs[5])[1]
+    b = make(1)                                   # different initial weights: everything must come from the checkpoint
+    b.load_state_dict(torch.load('/tmp/_taco_ckpt_test.pt', weights_only=True))
+    os.remove('/tmp/_taco_ckpt_test.pt')
+    for k in ('params', 'm', 'v', 'bn'):
+        assert torch.equal(getattr(b.engine, k).cpu(), sd[k]), k
+    assert int(b.engine.global_step.item()) == 5
+    out = step(b, bs[5])
+    assert out[0] == 6 and abs(out[1] - loss6) < 1e-5 * abs(loss6)
+    H.hparams.parse('outputs_per_step=2')
+    c = create_model('tacotron', H.hparams)
+    c.initialize(bs[0]['inputs'], bs[0]['input_lengths'], bs[0]['mel_targets'], bs[0]['linear_targets'])
+    with pytest.raises(ValueError, match='layout'):
+        c.load_state_dict(sd)
+    importlib.reload(H)
+
+
+def _toy_dataset(tmp_path, n=12):
+    import json
+    rng = np.random.RandomState(0)
+    lines = []
+    for i in range(n):
+        T = 23 + 3 * (i % 5)
+        paths = []
+        for kind, shape in (('spec', (T, 1025)), ('mel', (T, 80)), ('wav', (T * 250,))):
+            p = str(tmp_path / ('%s-%d.npy' % (kind, i)))
+            np.save(p, rng.rand(*shape).astype(np.float32))
+            paths.append(p)
+        lines.append(repr(paths + ['{%s}' % ' '.join('<sym%d>' % rng.randint(0, 7000) for _ in range(4 + i % 7)), i % 3]))
+    meta = tmp_path / 'toy_id_num_3.txt'
+    meta.write_text('\n'.join(lines) + '\n', encoding='utf-8')
+    (tmp_path / 'train_npy_data_dict.json').write_text(json.dumps({'TOY': str(meta)}))
+
+
+def _run_train(tmp_path, monkeypatch, extra):
+    import importlib
+    import sys
+    import hparams as H
+    importlib.reload(H)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(sys, 'argv', ['train.py', '--base_dir', str(tmp_path / 'logs'), '--train_data', 'TOY', '--description', 'toy',
+                                      '--hparams', 'batch_size=4,outputs_per_step=5,decay_learning_rate=false,initial_learning_rate=0.001'] + extra)
+    import train
+    importlib.reload(train)
+    train.main()
+    importlib.reload(H)
+    return (tmp_path / 'logs' / 'logs-tacotron-toy' / 'train.log').read_text()
+
+
+def test_train_py_restore_step_and_spike_rollback(tmp_path, monkeypatch):
+    """reference train.py:125-129 (--restore_step) and :154-160 (loss spike / NaN -> reload the checkpoint
+    int((step-10)/interval)*interval and carry on from there).
+    Run 1 writes model.ckpt-5 and stops at step 6.  Run 2 resumes from 5: its first step is 6.  Run 3 resumes from 5 and the
+    loss is forced to spike at step 18: the driver logs the recovery, reloads model.ckpt-5 (int((18-10)/5)*5) and the next
+    step is 6 again.  Run 4 (fresh log dir) spikes at step 3, before any checkpoint exists: the loader's error ends the run
+    (reference: saver.restore raises) instead of training on."""
+    _toy_dataset(tmp_path)
+    log1 = _run_train(tmp_path, monkeypatch, ['--max_steps', '6', '--checkpoint_interval', '5'])
+    assert 'Starting new training run' in log1 and 'Saving checkpoint to:' in log1
+    ck = tmp_path / 'logs' / 'logs-tacotron-toy'
+    assert (ck / 'model.ckpt-5').exists()
+    log2 = _run_train(tmp_path, monkeypatch, ['--restore_step', '5', '--max_steps', '8', '--checkpoint_interval', '5'])
+    new = log2[len(log1):]
+    assert 'Resuming from checkpoint:' in new and 'model.ckpt-5' in new
+    steps = [int(l.split('Step')[1].split('[')[0]) for l in new.splitlines() if 'avg_sec/step' in l]
+    assert steps[0] == 6 and steps[-1] == 8
+
+    import models.tacotron as MT
+    orig = MT.Tacotron.run_step
+    fired = []
+
+    def spiky_at(k):
+        def run_step(self):
+            out = orig(self)
+            if out is not None and out[0] == k and not fired:
+                fired.append(k)
+                return (out[0], out[1] * 100.0, out[2], out[3])
+            return out
+        return run_step
+    monkeypatch.setattr(MT.Tacotron, 'run_step', spiky_at(18))
+    log3 = _run_train(tmp_path, monkeypatch, ['--restore_step', '5', '--max_steps', '20', '--checkpoint_interval', '5'])
+    new = log3[len(log2):]
+    assert fired == [18] and 'recover to the previous checkpoint' in new
+    steps = [int(l.split('Step')[1].split('[')[0]) for l in new.splitlines() if 'avg_sec/step' in l]
+    assert steps[0] == 6 and steps[steps.index(18) + 1] == 6 and len(steps) == 20
+    assert 'Exiting due to exception' not in new
+
+    del fired[:]
+    monkeypatch.setattr(MT.Tacotron, 'run_step', spiky_at(3))
+    monkeypatch.setattr('sys.argv', [])
+    import importlib
+    import sys
+    import hparams as H
+    importlib.reload(H)
+    monkeypatch.setattr(sys, 'argv', ['train.py', '--base_dir', str(tmp_path / 'logs'), '--train_data', 'TOY', '--description', 'toy2',
+                                      '--hparams', 'batch_size=4,outputs_per_step=5', '--max_steps', '9', '--checkpoint_interval', '5'])
+    import train
+    importlib.reload(train)
+    train.main()
+    importlib.reload(H)
+    log4 = (tmp_path / 'logs' / 'logs-tacotron-toy2' / 'train.log').read_text()
+    assert fired == [3] and 'recover to the previous checkpoint' in log4 and 'Exiting due to exception' in log4
+    steps = [int(l.split('Step')[1].split('[')[0]) for l in log4.splitlines() if 'avg_sec/step' in l]
+    assert steps == [1, 2, 3]
+
+
+def test_data_parallel_exchange_plumbing_single_rank_rccl():
+    """The overlapped gradient exchange on the GPU with a real RCCL communicator of ONE rank (the box has one GPU): the engine
+    is told world = 2, so backward launches its four buckets out of band on the communication stream (all-reduce over one
+    rank = identity), allreduce_grads() joins them and the optimizer applies the 1/world factor inside its kernels.  The
+    result must equal the oracle's update with the gradient halved; the exchange order must be the backward order.
+    (Two or more ranks: tests/test_dp_gloo.py on CPU; no multi-GPU hardware in this pipeline -- unmeasured.)"""
+    import socket
+    import torch.distributed as dist
+    from oracle import tacotron_np as onp, tacotron_torch as ot
+    from tacotron_multispeaker_amd.engine import Engine
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        N, Ti, To, r = 4, 24, 60, 5
+        P = onp.init_params(seed=3, r=r)
+        b = onp.synth_batch(N, Ti, To, r, seed=8)
+        ts = ot.TrainState(P, torch.float64, r=r, tf_sparse_norm=False)
+        last = ts.forward_backward(b)
+        for k in last['grads']:
+            last['grads'][k] = last['grads'][k] * 0.5
+        info = ts.apply(last)
+        eng = Engine(r=r, named_params=P, tf_sparse_norm=False)
+        eng.world = 2
+        eng.exposed_events = []
+        eng.train_step(*dev_batch(b, eng.dev)[:4])
+        torch.cuda.synchronize()
+        eng.check_errors()
+        assert eng._exchange.order == [0, 1, 2, 3] and len(eng.exposed_events) == 1
+        assert eng.exposed_events[0][0].elapsed_time(eng.exposed_events[0][1]) >= 0.0
+        assert abs(float(eng.info[0].item()) - info['global_norm']) < 1e-4 * info['global_norm']
+        pn = eng.export_named('params')
+        for k, v in ts.P.items():
+            assert np.abs(pn[k] - v.detach().numpy()).max() < 1e-5, k
+    finally:
+        dist.destroy_process_group()
 
 
 def test_model_api_synthesis_mode():

@@ -42,8 +42,8 @@ def train(log_dir, args):
     hparams.num_GPU = max(len(GPUs_id), world)
     local = int(os.environ.get('LOCAL_RANK', str(GPUs_id[0])))
     torch.cuda.set_device(local)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
 
     coord = Coordinator()
@@ -68,6 +68,7 @@ def train(log_dir, args):
     model.engine.world = world
 
     step = 0
+    steps_run = 0                    # --max_steps also bounds the number of iterations, so a run that keeps rolling back ends
     time_window = ValueWindow(250)
     loss_window = ValueWindow(1000)
     try:
@@ -88,18 +89,32 @@ def train(log_dir, args):
             loss_window.append(loss)
             log('Step %-7d [%.03f avg_sec/step,  loss=%.05f,  avg_loss=%.05f,  lossw=%.05f]' % (
                 step, time_window.average, loss, loss_window.average, loss_regularity))
-            # if the gradient seems to explode, then restore to the previous step (reference :154-160)
-            if loss > 2 * loss_window.average or math.isnan(loss):
+            # if the gradient seems to explode, then restore to the previous step (reference :154-160).  Under data
+            # parallelism the replicas must take the same branch: the decision is the OR over ranks (each rank only sees the
+            # loss of its own shard), and a rank reads a checkpoint only after rank 0 has finished writing it.
+            spike = bool(loss > 2 * loss_window.average or math.isnan(loss))
+            if world > 1:
+                flag = torch.tensor([1 if spike else 0], device='cuda:%d' % local, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                spike = bool(flag.item())
+            if spike:
                 log('recover to the previous checkpoint')
                 restore_step = int((step - 10) / args.checkpoint_interval) * args.checkpoint_interval
                 restore_path = '%s-%d' % (checkpoint_path, restore_step)
-                if os.path.exists(restore_path):
-                    model.load_state_dict(torch.load(restore_path, weights_only=True))
+                # a missing checkpoint raises (like saver.restore at reference :159) instead of training on with NaN weights
+                model.load_state_dict(torch.load(restore_path, weights_only=True))
+                steps_run += 1
+                if args.max_steps and steps_run >= args.max_steps:
+                    coord.request_stop()
                 continue
-            if step % args.checkpoint_interval == 0 and rank == 0:
-                log('Saving checkpoint to: %s-%d' % (checkpoint_path, step))
-                torch.save(model.state_dict(), '%s-%d' % (checkpoint_path, step))
-            if args.max_steps and step >= args.max_steps:
+            if step % args.checkpoint_interval == 0:
+                if rank == 0:
+                    log('Saving checkpoint to: %s-%d' % (checkpoint_path, step))
+                    torch.save(model.state_dict(), '%s-%d' % (checkpoint_path, step))
+                if world > 1:
+                    dist.barrier()          # the file is complete before any rank may roll back to it
+            steps_run += 1
+            if args.max_steps and (step >= args.max_steps or steps_run >= args.max_steps):
                 coord.request_stop()
     except Exception as e:
         log('Exiting due to exception: %s' % e)
