@@ -13,8 +13,8 @@ from tacotron_multispeaker_amd._lib import lib
 fw = lib.load().taco_attn_cluster_xchg_slots(N, Ti)
 st = eng._bufs['xchg_attn'][fw - 16:fw].cpu().numpy().astype(np.float64)
 S = To // r
-names = ['loop/top', 'A compute+publish', 'A gather+barrier', 'B compute', 'B gather+bar', 'C compute', 'C gather+bar', 'D compute', 'D gather+bar',
-         'E query+bar', 'F scores+bar', 'E-gather+bar', 'G softmax+bar', 'H ctx part+bar', 'H final+gather+bar', '-']
+names = ['loop/top', 'A p1 dot+publish', 'A gather+barrier', 'B p2 dot+publish', 'B gather+bar', 'C gates dot+publish', 'C cand-x dot+gather+bar',
+         'D cand dot+publish', 'D gather+bar', 'E query+bar', 'F scores+publish+gh dot+gather+bar', '-', '-', 'GH softmax+ctx+publish', 'GH gather+bar', '-']
 tot = st.sum()
 for n, v in zip(names, st):
     print('%-22s %8.0f cycles/step  %5.1f%%' % (n, v / S, 100 * v / max(tot, 1)))

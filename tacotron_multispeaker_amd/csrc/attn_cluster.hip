@@ -244,7 +244,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             STAMP(1);
             gather_vec<32>(xP1, p1_l, p1_l + PLEN(256), w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(2);
         // ================= B: prenet dense_2 =================
         {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             STAMP(3);
             gather_vec<16>(xP2, p2_l, p2_l + PLEN(128), w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(4);
         // ================= C: GRU gates (the h part of the pre-activation was computed off the chain, see F) =================
         float cx0 = 0.f, cx1 = 0.f;                 // candidate: x part, computed while the r*h exchange is in flight
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             dot2<8>(p2_l, p2_l + PLEN(128), pA * 8, wcx, cx0, cx1);
             gather_vec<32>(xRH, rh_l, rh_l + PLEN(256), w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(6);
         // ================= D: candidate + new state =================
         {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             STAMP(7);
             gather_vec<32>(xH, h_l, h_l + PLEN(256), w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(8);
         // ================= E: query slice =================
         {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 if (ok[1]) p.q[so1 * 256 + 32 * w + cA] = a1;
             }
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(9);
         // ================= F: partial scores over this workgroup's 32 dims, all t =================
         // pass 1: own partials, published (and parked in a_l); then work that is off the dependent chain; pass 2: gather + reduce
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             const float tot2 = dpp_add<0xB1>(sum);
             if (half == 0) a_l[i] = tot2;
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(10);
         STAMP(11);
         // ================= G+H: softmax and context slice, one pass per wave, no barrier in between =================
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
         }
         STAMP(13);
         gather_vec<32>(xCTX, ctx_l, ctx_l + PLEN(256), w, epoch, tid, p.err);
-        __syncthreads();
+        lds_barrier();
         STAMP(14);
     }
     STAMP_OUT(p.xchg + (long)nclus * (per_clu + CW));
@@ -555,7 +555,9 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     for (int i = tid; i < 2 * Ti * 8; i += AT) {
         const int c4 = i & 7, t = (i >> 3) % Ti, row = (i >> 3) / Ti;
         const long g = ((rw[row] * Ti) + t) * 256 + 32 * w + c4 * 4;
-        *reinterpret_cast<float4*>(K_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.keys + g);
+        // key tile: 16-byte chunks of row t rotated by t & 7 (column d at (d + 4 * (t & 7)) & 31): the dq product reads
+        // (t = tp + 8 i, d) from lanes (d & 3 | tp) of a 32-lane half -> 32 distinct banks (as the memory tile of the forward)
+        *reinterpret_cast<float4*>(K_l + (row * Ti + t) * 32 + ((c4 + t) & 7) * 4) = *reinterpret_cast<const float4*>(p.keys + g);
         *reinterpret_cast<float4*>(M_l + (row * Ti + t) * 32 + c4 * 4) = *reinterpret_cast<const float4*>(p.mem + g);
     }
 
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) w1[k] = p.w1c[(long)jA * 256 + pA * 16 + k];
-    const float vd = p.v[32 * w + (tid & 31)];            // dq mapping: d = tid & 31
+    const float vd = p.v[32 * w + 8 * ((tid >> 6) & 3) + ((tid & 63) >> 3)];      // dq mapping: d = 8 (wave & 3) + (lane >> 3)
 
     // exchange regions: DA [8][2Ti]; DQ, DCP [2][256]; DGR, DGU [2][256]; DP2 [2][128]; DP1 [2][256]
     const long per_clu = (long)CW * 2 * Ti + 2 * 256 * 5 + 2 * 128;
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             if (ok[0]) p.dctx[so[0] * 256 + jA] = d0;
             if (ok[1]) p.dctx[so[1] * 256 + jA] = d1;
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
             const int half = tid & 1, row = i >= Ti;
             const float* mp = M_l + i * 32 + half * 16;
@@ -679,53 +681,57 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             const float tot2 = dpp_add<0xB1>(sum);
             if (half == 0) de_l[i] = tot2;                        // da[row][t]
         }
-        __syncthreads();
-        // ================= X2: softmax backward: de = a * (da - sum a*da) =================
-        if (tid < 128) {
-            const int row = tid >> 6, lane = tid & 63;
-            float* dr_ = de_l + row * Ti;
-            const float* ar = a_l + row * Ti;
-            if (p.da_ext) {                                       // regulariser gradient wrt a_s (off by default)
-                const float* ex = p.da_ext + so[row] * (unsigned)Ti;
-                for (int t = lane; t < Ti; t += 64) dr_[t] += ex[t];
-            }
-            float dot = 0.f;
-            for (int t = lane; t < Ti; t += 64) dot = fmaf(ar[t], dr_[t], dot);
-            dot = wave_sum_fast(dot);
-            for (int t = lane; t < Ti; t += 64) dr_[t] = ar[t] * (dr_[t] - dot);
-        }
-        __syncthreads();
-        for (int i = tid; i < 2 * Ti; i += AT) {
-            const int row = i >= Ti, t = i - row * Ti;
-            if ((t & 7) == w && ok[row]) p.de[so[row] * Ti + t] = de_l[i];
-        }
-        // ================= X3: dq slice: dq[d] = v_d * sum_t de[t] * (1 - tanh^2(K[t,d] + q[d])) =================
+        lds_barrier();
+        // ================= X2+X3: softmax backward and dq slice, one pass per wave, no barrier in between =================
+        // Wave v works on row v >> 2 and score dims 8 (v & 3) .. +8.  Every wave of a row recomputes de = a * (da - sum a*da)
+        // for the whole row (the four waves write the same bits to ep_l and read back only their own writes), then
+        // dq[d] = v_d * sum_t de[t] * (1 - tanh^2(K[t,d] + q[d])): lane (d & 7 | tp) sums t = tp, tp + 8, ..., DPP adds combine
+        // the 8 tp lanes.
         {
-            const int row = tid >> 8, tp = (tid >> 5) & 7, d = tid & 31;
-            const float* er = de_l + row * Ti;
-            const float* kr = K_l + row * Ti * 32 + d;
-            const float qd = q_l[row * 32 + d];
+            const int wv = tid >> 6, lane = tid & 63;
+            const int row = wv >> 2;
+            const float* dr_ = de_l + row * Ti;
+            const float* ar = a_l + row * Ti;
+            float* er = ep_l + row * Ti;
+            float dv[8], av[8];                            // Ti <= 512 values per row live in registers
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = lane + 64 * i;
+                dv[i] = 0.f; av[i] = 0.f;
+                if (t < Ti) {
+                    dv[i] = dr_[t]; av[i] = ar[t];
+                    if (p.da_ext) dv[i] += p.da_ext[so[row] * (unsigned)Ti + t];      // regulariser gradient wrt a_s (off by default)
+                    dot = fmaf(av[i], dv[i], dot);
+                }
+            }
+            dot = wave_sum_fast(dot);
+            const bool wr = (wv & 3) == 0 && (lane & 7) == w && ok[row];       // member w stores t = w, w + 8, ... to HBM
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = lane + 64 * i;
+                if (t < Ti) { const float de = av[i] * (dv[i] - dot); er[t] = de; if (wr) p.de[so[row] * (unsigned)Ti + t] = de; }
+            }
+            const int tp = lane & 7, dl = 8 * (wv & 3) + (lane >> 3);
+            const float* kr = K_l + row * Ti * 32;
+            const float qd = q_l[row * 32 + dl];
             float acc0 = 0.f, acc1 = 0.f;
             int t = tp;
             for (; t + 8 < Ti; t += 16) {
-                const float th0 = fast_tanh(kr[t * 32] + qd), th1 = fast_tanh(kr[(t + 8) * 32] + qd);
+                const float th0 = fast_tanh(kr[t * 32 + ((dl + 4 * tp) & 31)] + qd), th1 = fast_tanh(kr[(t + 8) * 32 + ((dl + 4 * tp) & 31)] + qd);
                 acc0 = fmaf(er[t], 1.f - th0 * th0, acc0); acc1 = fmaf(er[t + 8], 1.f - th1 * th1, acc1);
             }
-            for (; t < Ti; t += 8) { const float th = fast_tanh(kr[t * 32] + qd); acc0 = fmaf(er[t], 1.f - th * th, acc0); }
-            cp_l[tp * 64 + row * 32 + d] = (acc0 + acc1) * vd;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int row = tid >> 5, d = tid & 31, j = 32 * w + d;
-            float x = 0.f;
-#pragma unroll
-            for (int tp = 0; tp < 8; ++tp) x += cp_l[tp * 64 + tid];
-            dq_l[row * PLEN(256) + PIDX(j)] = x;
-            put_gi(xDQ, (unsigned)(row * 256 + j), epoch, x, local);
-            if (ok[row]) p.dq[so[row] * 256 + j] = x;
+            if (t < Ti) { const float th = fast_tanh(kr[t * 32 + ((dl + 4 * tp) & 31)] + qd); acc0 = fmaf(er[t], 1.f - th * th, acc0); }
+            const float x = group_sum<8>(acc0 + acc1) * vd;
+            if (tp == 0) {
+                const int j = 32 * w + dl;
+                dq_l[row * PLEN(256) + PIDX(j)] = x;
+                put_gi(xDQ, (unsigned)(row * 256 + j), epoch, x, local);
+                if (ok[row]) p.dq[so[row] * 256 + j] = x;
+            }
         }
         gather_vec<32>(xDQ, dq_l, dq_l + PLEN(256), w, epoch, tid, p.err);
-        __syncthreads();
+        lds_barrier();
         // ================= X4: dhT = dh_ext + carry + dq . Wq^T ; candidate pre-activation gradient =================
         float dhT[2] = {0, 0}, du[2] = {0, 0}, dhd[2] = {0, 0};
         {
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             }
             gather_off<32>(xDCP, dxp_l, dxp_l + PLEN(768), 512, w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         // ================= X5: drh = dcp . Whc^T ; gate pre-activation gradients =================
         float dhp[2] = {0, 0};
         {
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             }
             gather2<32>(xDGR, xDGU, dxp_l, dxp_l + PLEN(768), 0, 256, w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- issue the loads for step s-1 (consumed at the top of the next iteration)
         if (s > p.s0) {
             const unsigned sn[2] = {so[0] - 1u, so[1] - 1u};
@@ -784,12 +790,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                                     }
             }
         }
-        // ================= X6: dh carry = dhp + dg . Whg^T ;  dp2pre = (dxp . Wx^T) * (p2 > 0) =================
+        // ================= X6: dp2pre = (dxp . Wx^T) * (p2 > 0) ;  dh carry = dhp + dg . Whg^T (off the chain) =================
         {
-            float a0 = 0.f, a1 = 0.f;
-            dot2<32>(dxp_l, dxp_l + PLEN(768), pA * 32, wg, a0, a1);
-            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
-            if (pA == 0) { dhc0 = dhp[0] + a0; dhc1 = dhp[1] + a1; }
             float b0 = 0.f, b1 = 0.f;
             if constexpr (WLDS) dot2_lds<24>(dxp_l, dxp_l + PLEN(768), pB * 24, W_l, tid, b0, b1);
             else dot2<24>(dxp_l, dxp_l + PLEN(768), pB * 24, wx, b0, b1);
@@ -801,9 +803,14 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 if (ok[0]) p.dp2[so[0] * 128 + jB] = b0;
                 if (ok[1]) p.dp2[so[1] * 128 + jB] = b1;
             }
+            // the recurrent carry is first needed in X4 of the next step: computed while the dp2 granules travel
+            float a0 = 0.f, a1 = 0.f;
+            dot2<32>(dxp_l, dxp_l + PLEN(768), pA * 32, wg, a0, a1);
+            a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
+            if (pA == 0) { dhc0 = dhp[0] + a0; dhc1 = dhp[1] + a1; }
             gather_vec<16>(xDP2, dp2_l, dp2_l + PLEN(128), w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         // ================= X7: dp1pre = (dp2pre . W2^T) * (p1 > 0) =================
         {
             float a0 = 0.f, a1 = 0.f;
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             }
             gather_vec<32>(xDP1, dp1_l, dp1_l + PLEN(256), w, epoch, tid, p.err);
         }
-        __syncthreads();
+        lds_barrier();
         if (s > p.s0) {
             if (pA == 0) { pf_p1[0] = p.p1[(so[0] - 1u) * 256u + jA]; pf_p1[1] = p.p1[(so[1] - 1u) * 256u + jA]; }
             if (pB == 0) { pf_p2[0] = p.p2[(so[0] - 1u) * 128u + jB]; pf_p2[1] = p.p2[(so[1] - 1u) * 128u + jB]; }

@@ -87,6 +87,15 @@ __device__ __forceinline__ float wave_max_fast(float v) {
                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
 }
 
+// Workgroup barrier for the step loops of the persistent recurrence kernels: orders LDS traffic only.  __syncthreads() also
+// drains the vector-memory counter (s_waitcnt vmcnt(0)), i.e. every barrier would wait for the step's global stores of saved
+// activations (write acknowledgements, ~300-500 cycles) and for the one-step-ahead prefetch loads (an Infinity-Cache / HBM
+// round trip, 550-900 cycles) although nothing on the dependent chain needs them: threads of a workgroup never read global
+// data written by other threads of the same launch, and a prefetched value is waited for by the compiler at its first use.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 64-lane wavefront reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
             if (gcol < H) rh_l[LIDX(gcol)] = g * h_l[LIDX(gcol)];
             else u_l[gcol - H] = g;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- candidate + state update
         float b;
         {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
             orow[(long)t * p.ldo + ccol] = valid ? hn : 0.0f;
             h_l[LIDX(ccol)] = valid ? hn : hprev;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
         float dh_new = valid ? dhT * u : dh;
         const float dcp = dhT * (1.0f - u) * (1.0f - c * c);
         if (owner) dcp_l[LIDX(k)] = dcp;
-        __syncthreads();
+        lds_barrier();
         // ---- drh[k] = sum_j dcp[j] * Wc[k][j]
         float drh;
         {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
             hprow[(long)t * H + k] = hprev;
             rhrow[(long)t * H + k] = r * hprev;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- dh_{prev}[k] += sum_j dg[j] * Wg[k][j]   (j over 256, quarter of 64 per lane)
         float e;
         {

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
             }
         }
         gather256(xr, rh_l[0], rh_l[1], 0, w, epoch, tid, p.err);
-        __syncthreads();
+        lds_barrier();
         // ---- candidate + state for hidden index jc (both rows), K eighth per lane
         float c0, c1;
         {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
             }
         }
         gather256(xh, h_l[0], h_l[1], 0, w, epoch, tid, p.err);
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
             }
         }
         gather256(xc, dx_l[0], dx_l[1], 512, w, epoch, tid, p.err);
-        __syncthreads();
+        lds_barrier();
         // ---- drh[k_own] = sum_j dcp[j] * Whc[k_own][j]  (eighth per lane, both rows)
         float d0, d1;
         {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
                 dx_l[row][QIDX(HD + j)] = v[1];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- dh_{s-1}[k_own] = dhp + sum_j dg[j] * Whg[k_own][j]   (j over 512, eighth of 64 per lane)
         float e0, e1;
         {
