@@ -133,6 +133,9 @@ def cpu_baseline(P, N, Ti, To, r, id_num, steps=3):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a share of 16 CPUs whatever the host's core count: more threads than that only
+    # oversubscribe the quota (a 200+-thread run of this step did not finish within 7 minutes)
+    cores = min(cores, int(os.environ.get('TACO_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
     ts = ot.TrainState(P, torch.float32, id_num=id_num, r=r)
     ts.step(onp.synth_batch(2, 32, 40, r, seed=1, id_num=id_num))         # warm-up (tiny)
@@ -144,12 +147,13 @@ def cpu_baseline(P, N, Ti, To, r, id_num, steps=3):
     dt = (time.time() - t) / steps
     return dict(value=N * To / dt, unit='mel-frames/sec', cores=cores, cpu=cpu_model(), kind='port', sec_per_step=dt,
                 sample='%d full training steps (after 1 warm-up) of the bench batch (N=%d,T_in=%d,T_out=%d,r=%d), fp32 PyTorch-CPU '
-                       'restatement (oracle/tacotron_torch.py) on %d threads; TF-1 unavailable' % (steps, N, Ti, To, r, cores))
+                       'restatement (oracle/tacotron_torch.py) on %d threads (the CPU share of a 1-GPU job on this box; host has %d logical CPUs); TF-1 unavailable' % (steps, N, Ti, To, r, cores, os.cpu_count() or 0))
 
 
 def parity_vs_oracle(eng, P, batch, r, id_num):
     """mel / linear outputs of the HIP forward vs the fp32 CPU restatement on the same weights and batch."""
     from oracle import tacotron_torch as ot
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     Pt = ot.to_torch(P, torch.float32, requires_grad=False)
     with torch.no_grad():
         ref = ot.forward(Pt, batch['inputs'], batch['input_lengths'], torch.tensor(batch['mel_targets']), batch['identities'],
