@@ -42,6 +42,18 @@ int taco_conv_gemm_bwd_weight(const float* X, const float* dY, float* dW, int M,
 int taco_gemm_tn_shift(const float* X, const float* dY, float* dW, int M, int T, int K, int N, int ldx, int lddy,
                        int ldw, int shift, hipStream_t stream);
 
+/* Grouped weight gradients: `count` independent problems of taco_conv_gemm_bwd_weight (shift = 0) / taco_gemm_tn_shift in ONE
+ * launch (the problem table travels in the kernel arguments; problems that need another tile configuration are launched on
+ * their own).  items is a HOST array, read before the call returns. */
+typedef struct TacoWgrad {
+    const float* X; const float* dY; float* dW;
+    int M, T, Cin, Cout, kw, bank_K, ldx, lddy, ldw, shift;
+} TacoWgrad;
+int taco_wgrad_group(const TacoWgrad* items, int count, hipStream_t stream);
+/* the same for bias gradients: out_i[c] += sum_m x_i[m, c] for `count` tensors in one launch (HOST array) */
+typedef struct TacoColSum { const float* x; float* out; int ldx, M, C; } TacoColSum;
+int taco_col_sum_group(const TacoColSum* items, int count, hipStream_t stream);
+
 /* dense layer forward / input gradient over the step chunk [s0, s1) of [N,S,*] tensors (rows (n,s) live at n*S + s);
  * lets the hoisted decoder projections be issued chunk by chunk between pipelined recurrence launches */
 int taco_dense_rows_fwd(const float* X, const float* W, const float* bias, float* Y, int N, int S, int s0, int s1, int Cin,

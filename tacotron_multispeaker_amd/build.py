@@ -9,7 +9,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libtaco_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DTACO_STAMP'] if os.environ.get('TACO_STAMP') else [])
+FLAGS = (['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DTACO_STAMP'] if os.environ.get('TACO_STAMP') else [])
+         + os.environ.get('HIPCC_EXTRA', '').split())        # developer experiments (scripts/dev_*.sh)
 
 
 def sources():

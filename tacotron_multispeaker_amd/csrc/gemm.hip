@@ -839,7 +839,7 @@ struct MmaKs {
 };
 
 template <int BM, int BN, int BK, int STAGES>
-__global__ __launch_bounds__(256) void conv_gemm_tn2(ConvGemm p) {
+__device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const int by, const int bz) {
     constexpr int ASZ = BK * BM, BSZ = BK * BN, SSZ = ASZ + BSZ;
     constexpr int RA = 256 / BM, RBn = 256 / BN;            // rows per wave-instruction (1 KiB)
     constexpr int NVA = BK / (RA * 4), NVB = BK / (RBn * 4), LPS = NVA + NVB;
@@ -848,9 +848,9 @@ __global__ __launch_bounds__(256) void conv_gemm_tn2(ConvGemm p) {
     __shared__ __attribute__((aligned(16))) float smem[STAGES][SSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int c0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    int seg = blockIdx.z / p.splitk;
-    const int split = blockIdx.z - seg * p.splitk;
+    const int c0 = bx * BM, n0 = by * BN;
+    int seg = bz / p.splitk;
+    const int split = bz - seg * p.splitk;
     int kw = p.kw_lo, j = seg;
     if (p.bank) { kw = 1; while (seg >= kw) { seg -= kw; ++kw; } j = seg; }
     const int shift = j - (kw - 1) / 2 + p.shift0;
@@ -959,6 +959,33 @@ __global__ __launch_bounds__(256) void conv_gemm_tn2(ConvGemm p) {
                 if (row < p.K) atomicAdd(Cw + (long)row * ldc + col, acc[mi][ni][r]);
             }
     }
+}
+
+template <int BM, int BN, int BK, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_tn2(ConvGemm p) {
+    tn2_body<BM, BN, BK, STAGES>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped weight-gradient launch: ONE grid walks the tiles of up to TACO_WG_MAX independent dW problems (largest first).
+// Backward produces 44 weight-gradient GEMMs per step, most of them 10-40 us: launched one by one on the side stream their
+// launch gaps and ramp-up/drain phases are a third of the stream's time and every launch is a new burst of workgroups
+// competing with the latency-bound recurrence kernels.  The problem table travels in the kernel arguments (no device table,
+// no host->device copy, HIP-graph capturable).
+#define TACO_WG_MAX 32
+struct WgradGroup {
+    int count;
+    int first[TACO_WG_MAX + 1];                 // first[i] = index of problem i's first workgroup; first[count] = grid size
+    unsigned short gx[TACO_WG_MAX], gy[TACO_WG_MAX];
+    ConvGemm p[TACO_WG_MAX];
+};
+static_assert(sizeof(WgradGroup) <= 4096, "kernel argument block");
+template <int BM, int BN, int BK, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_tn2_group(WgradGroup g) {
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.count && b >= g.first[i + 1]) ++i;      // wave-uniform scan of <= 32 kernel-argument words
+    const int r = b - g.first[i], gx = g.gx[i], gy = g.gy[i];
+    tn2_body<BM, BN, BK, STAGES>(g.p[i], r % gx, (r / gx) % gy, r / (gx * gy));
 }
 
 // ---- host-side dispatch --------------------------------------------------------------------------------
@@ -1141,10 +1168,12 @@ extern "C" int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* d
     TACO_RETURN_LAST();
 }
 
-static int conv_gemm_bwd_weight_impl(const float* X, const float* dY, float* dW, int M, int T, int Cin, int Cout,
-                                     int kw, int bank_K, int ldx, int lddy, int ldw, int shift0, hipStream_t stream) {
+// plans one weight-gradient problem: fills p and the launch grid; cfg: 0 = v2 64x64x32 (3 stages; the grouped kernel's
+// configuration), 1 = v2 64x64x32 2 stages (short loops), 2 = v2 128x128x16, 3 = v1 64, 4 = v1 128
+static int plan_bwd_weight(ConvGemm& p, dim3& g, int& cfg, const float* X, const float* dY, float* dW, int M, int T, int Cin,
+                           int Cout, int kw, int bank_K, int ldx, int lddy, int ldw, int shift0, int wgs_target) {
     // dW must be zero-initialised (or hold a running sum): partial sums are atomically ADDED.
-    ConvGemm p{};
+    p = ConvGemm{};
     p.shift0 = shift0;
     p.A = X; p.B = dY; p.C = dW; p.bias = nullptr;
     p.M = M; p.K = Cin; p.T = T; p.lda = ldx; p.ldb = lddy;
@@ -1155,28 +1184,84 @@ static int conv_gemm_bwd_weight_impl(const float* X, const float* dY, float* dW,
     if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
     // Measured with scripts/gemm_bench.hip (MODE=bwd_weight) on MI355X: with the v2 kernel 64x64x32 tiles match or beat
     // 128x128x16 on every model shape (fewer atomics per output element at equal workgroup count); big tiles only pay
-    // for >= 512 of them.  The reduction is split until ~2048 workgroups exist, keeping >= 12 row tiles per workgroup.
-    static const int tn_big = env_int("TACO_TN_BIG", -1), tn_wgs = env_int("TACO_TN_WGS", 2048);
+    // for >= 512 of them.  The reduction is split until ~wgs_target workgroups exist, keeping >= 12 row tiles per workgroup.
+    static const int tn_big = env_int("TACO_TN_BIG", -1);
     const bool big = tn_big >= 0 ? tn_big != 0
                                  : (p.K >= 128 && p.N >= 128 && (long)cdiv(p.K, 128) * cdiv(p.N, 128) * nseg >= 512);
     const int bm = big ? 128 : 64, bk = big ? 16 : 32;
     const long tiles = (long)cdiv(p.K, bm) * cdiv(p.N, bm) * nseg;
     const int ktiles = cdiv(M, bk);
-    int splitk = (int)((tn_wgs + tiles - 1) / tiles);
+    int splitk = (int)((wgs_target + tiles - 1) / tiles);
     const int max_split = ktiles / 12 > 0 ? ktiles / 12 : 1;
     if (splitk > max_split) splitk = max_split;
     if (splitk < 1) splitk = 1;
     p.splitk = splitk;
-    dim3 g(cdiv(p.K, bm), cdiv(p.N, bm), nseg * splitk);
+    g = dim3(cdiv(p.K, bm), cdiv(p.N, bm), nseg * splitk);
     static const int force_v1 = env_int("TACO_TN_V1", 0);
     // v2 needs 31-bit byte offsets into X (plus the shifted rows) and dY
     const bool v2 = !force_v1 && ((long)M + 64) * ldx * 4 < (1L << 31) && ((long)M + 64) * lddy * 4 < (1L << 31);
-    if (!v2) {
-        if (big) hipLaunchKernelGGL((conv_gemm_tn<128, 128, 16>), g, dim3(256), 0, stream, p);
-        else     hipLaunchKernelGGL((conv_gemm_tn<64, 64, 32>), g, dim3(256), 0, stream, p);
-    } else if (big) hipLaunchKernelGGL((conv_gemm_tn2<128, 128, 16, 3>), g, dim3(256), 0, stream, p);
-    else if (cdiv(ktiles, splitk) <= 8) hipLaunchKernelGGL((conv_gemm_tn2<64, 64, 32, 2>), g, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_gemm_tn2<64, 64, 32, 3>), g, dim3(256), 0, stream, p);
+    cfg = !v2 ? (big ? 4 : 3) : big ? 2 : (cdiv(ktiles, splitk) <= 8 ? 1 : 0);
+    return TACO_OK;
+}
+
+static void launch_bwd_weight(const ConvGemm& p, dim3 g, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 4: hipLaunchKernelGGL((conv_gemm_tn<128, 128, 16>), g, dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((conv_gemm_tn<64, 64, 32>), g, dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((conv_gemm_tn2<128, 128, 16, 3>), g, dim3(256), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((conv_gemm_tn2<64, 64, 32, 2>), g, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((conv_gemm_tn2<64, 64, 32, 3>), g, dim3(256), 0, stream, p);
+    }
+}
+
+static int conv_gemm_bwd_weight_impl(const float* X, const float* dY, float* dW, int M, int T, int Cin, int Cout,
+                                     int kw, int bank_K, int ldx, int lddy, int ldw, int shift0, hipStream_t stream) {
+    static const int tn_wgs = env_int("TACO_TN_WGS", 2048);
+    ConvGemm p; dim3 g; int cfg;
+    if (int e = plan_bwd_weight(p, g, cfg, X, dY, dW, M, T, Cin, Cout, kw, bank_K, ldx, lddy, ldw, shift0, tn_wgs)) return e;
+    launch_bwd_weight(p, g, cfg, stream);
+    TACO_RETURN_LAST();
+}
+
+// Grouped form (see conv_gemm_tn2_group): every problem that fits the 64x64x32 v2 configuration joins a group of <=
+// TACO_WG_MAX problems, ordered by work (largest first, so the long tiles start early and the short ones fill the tail);
+// the others (128-wide tiles, > 2 GiB operands) are launched on their own.
+extern "C" int taco_wgrad_group(const TacoWgrad* items, int count, hipStream_t stream) {
+    if (!items || count < 0) return TACO_EINVAL;
+    // a group shares the chip: the per-problem split targets fewer workgroups than a lone launch would
+    static const int grp_wgs = env_int("TACO_TN_GROUP_WGS", 1024);
+    struct Planned { ConvGemm p; dim3 g; double work; };
+    Planned pl[TACO_WG_MAX];
+    int n = 0;
+    auto flush = [&]() {
+        if (!n) return;
+        for (int a = 1; a < n; ++a) {                     // insertion sort, descending work
+            Planned t = pl[a]; int b = a - 1;
+            while (b >= 0 && pl[b].work < t.work) { pl[b + 1] = pl[b]; --b; }
+            pl[b + 1] = t;
+        }
+        WgradGroup grp;
+        grp.count = n;
+        int first = 0;
+        for (int a = 0; a < n; ++a) {
+            grp.first[a] = first; grp.gx[a] = (unsigned short)pl[a].g.x; grp.gy[a] = (unsigned short)pl[a].g.y; grp.p[a] = pl[a].p;
+            first += (int)(pl[a].g.x * pl[a].g.y * pl[a].g.z);
+        }
+        for (int a = n; a <= TACO_WG_MAX; ++a) grp.first[a] = first;
+        hipLaunchKernelGGL((conv_gemm_tn2_group<64, 64, 32, 3>), dim3(first), dim3(256), 0, stream, grp);
+        n = 0;
+    };
+    for (int i = 0; i < count; ++i) {
+        const TacoWgrad& it = items[i];
+        ConvGemm p; dim3 g; int cfg;
+        if (int e = plan_bwd_weight(p, g, cfg, it.X, it.dY, it.dW, it.M, it.T, it.Cin, it.Cout, it.kw, it.bank_K, it.ldx, it.lddy,
+                                    it.ldw, it.shift, grp_wgs)) return e;
+        if (cfg > 1 || g.x > 65535 || g.y > 65535) { launch_bwd_weight(p, g, cfg, stream); continue; }
+        pl[n].p = p; pl[n].g = g;
+        pl[n].work = (double)g.x * g.y * g.z * cdiv(cdiv(it.M, 32), p.splitk);
+        if (++n == TACO_WG_MAX) flush();
+    }
+    flush();
     TACO_RETURN_LAST();
 }
 

@@ -16,6 +16,15 @@ import torch
 from ._lib import lib
 from .params import ParamLayout, init_named
 
+class TacoWgrad(ctypes.Structure):          # include/taco_hip.h
+    _fields_ = [('X', ctypes.c_void_p), ('dY', ctypes.c_void_p), ('dW', ctypes.c_void_p)] + \
+               [(n, ctypes.c_int) for n in ('M', 'T', 'Cin', 'Cout', 'kw', 'bank_K', 'ldx', 'lddy', 'ldw', 'shift')]
+
+
+class TacoColSum(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('ldx', ctypes.c_int), ('M', ctypes.c_int), ('C', ctypes.c_int)]
+
+
 BN_EPS = 1e-3        # tf.layers.batch_normalization defaults
 BN_MOMENTUM = 0.99
 
@@ -91,16 +100,22 @@ class Engine:
         self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._bufs = {}
         self._dpos = 0
-        self.side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, int(os.environ.get('TACO_SIDE_STREAMS', '1'))))]
+        # Stream priorities: the weight-gradient GEMMs of the side stream(s) are bulk work with slack; queued at the same priority
+        # as the critical path their big grids hold the dispatcher while short critical kernels (highway / BN chains, the next
+        # recurrence chunk) wait behind them.  TACO_PRIO = "<critical>:<side>" (HIP: lower number = higher priority).
+        pr = [int(x) for x in os.environ.get('TACO_PRIO', '0:0').split(':')]
+        self.side_streams = [torch.cuda.Stream(device=self.dev, priority=pr[1]) for _ in range(max(1, int(os.environ.get('TACO_SIDE_STREAMS', '1'))))]
         self._side_rr = 0
         self._side_active = False
         self._deferred = []
-        self.stream_b = torch.cuda.Stream(device=self.dev)      # decoder pipeline stages (GRU1 / GRU2 or attention)
-        self.stream_c = torch.cuda.Stream(device=self.dev)
+        self.stream_b = torch.cuda.Stream(device=self.dev, priority=pr[0])      # decoder pipeline stages (GRU1 / GRU2 or attention)
+        self.stream_c = torch.cuda.Stream(device=self.dev, priority=pr[0])
+        self.main_stream = torch.cuda.Stream(device=self.dev, priority=pr[0]) if pr[0] != 0 else None
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
         self.last_chunk_frac = float(os.environ.get('TACO_LAST_CHUNK', '0.5'))     # last chunk length / (S / chunks)
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
+        self.group_wgrad = os.environ.get('TACO_GROUP_WGRAD', '1') != '0'      # grouped weight / bias gradient launches
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
         self.world = 1                 # data-parallel replicas (set by train.py / bench.py after init_process_group)
         self.comm_stream = torch.cuda.Stream(device=self.dev)    # bucket all-reduces are ordered behind this stream
@@ -159,6 +174,13 @@ class Engine:
     # ---- optional in-step kernel timing (bench.py): HIP events around every launch of a kernel family, recorded on the stream
     # the kernel is launched on; ktime = None (default) costs nothing
     ktime = None
+    sections = None          # dev: list of (name, event) recorded on the main stream at stage boundaries (scripts/dev_sections.py)
+
+    def _mark(self, name):
+        if self.sections is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.sections.append((name, e))
 
     def _timed(self, family, flops, fn):
         if self.ktime is None:
@@ -190,8 +212,38 @@ class Engine:
     # and fill the CUs that the latency-bound persistent recurrence kernels leave idle.
     def _side(self, fn):
         if not self._side_active:
-            return fn()
+            return self._emit([fn]) if isinstance(fn, tuple) else fn()
         self._deferred.append(fn)          # released by flush_side() when a recurrence kernel has just been launched
+
+    def _emit(self, items):
+        """Launch a run of deferred weight-gradient ('dw', ...) / bias-gradient ('cs', ...) descriptors on the current stream:
+        ONE grouped launch each (taco_wgrad_group / taco_col_sum_group; TACO_GROUP_WGRAD=0: one launch per problem)."""
+        dw = [it for it in items if it[0] == 'dw']
+        cs = [it for it in items if it[0] == 'cs']
+        if dw:
+            arr = (TacoWgrad * len(dw))()
+            fl = 0.0
+            for a, (_, X, dY, dW, M, T, Cin, Cout, kw, bank, ldx, lddy, ldw, shift, flops) in zip(arr, dw):
+                a.X, a.dY, a.dW = X.data_ptr(), dY.data_ptr(), dW.data_ptr()
+                a.M, a.T, a.Cin, a.Cout, a.kw, a.bank_K, a.ldx, a.lddy, a.ldw, a.shift = M, T, Cin, Cout, kw, bank, ldx, lddy, ldw, shift
+                fl += flops
+            if self.group_wgrad:
+                self._timed('dW GEMM (conv_gemm_tn2_group)', fl, lambda: lib.taco_wgrad_group(ctypes.addressof(arr), len(dw), self.st))
+            else:
+                for a in arr:
+                    if a.shift:
+                        lib.taco_gemm_tn_shift(a.X, a.dY, a.dW, a.M, a.T, a.Cin, a.Cout, a.ldx, a.lddy, a.ldw, a.shift, self.st)
+                    else:
+                        lib.taco_conv_gemm_bwd_weight(a.X, a.dY, a.dW, a.M, a.T, a.Cin, a.Cout, a.kw, a.bank_K, a.ldx, a.lddy, a.ldw, self.st)
+        if cs:
+            arr = (TacoColSum * len(cs))()
+            for a, (_, x, ldx, out, M, C) in zip(arr, cs):
+                a.x, a.out, a.ldx, a.M, a.C = x.data_ptr(), out.data_ptr(), ldx, M, C
+            if self.group_wgrad:
+                lib.taco_col_sum_group(ctypes.addressof(arr), len(cs), self.st)
+            else:
+                for a in arr:
+                    lib.taco_col_sum(a.x, a.ldx, a.out, a.M, a.C, self.st)
 
     def flush_side(self):
         """Enqueue the pending weight-gradient work on the side stream.  Called right AFTER a persistent recurrence
@@ -203,15 +255,28 @@ class Engine:
         ev.record()
         for ss in self.side_streams:
             ss.wait_event(ev)
-        # independent weight-gradient launches (distinct outputs, atomic accumulation) are dealt round-robin over the side
-        # streams, so that the many short ones at the end of backward do not serialise behind each other
+        # runs of weight / bias gradient descriptors become grouped launches; with several side streams the runs are dealt
+        # round-robin
+        run = []
+
+        def emit_run():
+            if run:
+                with torch.cuda.stream(self.side_streams[self._side_rr % len(self.side_streams)]):
+                    self._emit(run)
+                self._side_rr += 1
+                del run[:]
         for fn in self._deferred:
+            if isinstance(fn, tuple) and fn[0] in ('dw', 'cs'):
+                run.append(fn)
+                continue
+            emit_run()
             if isinstance(fn, tuple):      # ('bucket', go): every producer of a gradient bucket is now enqueued
                 fn[1]()
                 continue
             with torch.cuda.stream(self.side_streams[self._side_rr % len(self.side_streams)]):
                 fn()
             self._side_rr += 1
+        emit_run()
         self._deferred = []
 
     # ---- data-parallel exchange overlapped with backward (tacotron_multispeaker_amd/dp.py) --------------
@@ -239,16 +304,14 @@ class Engine:
             go()
 
     def gemm_dw(self, X, dY, dW, M, Cin, Cout, T=None, kw=1, bank=0, ldx=None, lddy=None, ldw=None):
-        self._side(lambda: self._timed('dW GEMM (conv_gemm_tn2)', self._gemm_flops(M, Cin, Cout, kw, bank),
-                                       lambda: lib.taco_conv_gemm_bwd_weight(X, dY, dW, M, T or M, Cin, Cout, kw, bank,
-                                                                             ldx or X.stride(-2), lddy or dY.stride(-2), ldw or Cout, self.st)))
+        self._side(('dw', X, dY, dW, M, T or M, Cin, Cout, kw, bank, ldx or X.stride(-2), lddy or dY.stride(-2), ldw or Cout, 0,
+                    self._gemm_flops(M, Cin, Cout, kw, bank)))
 
     def gemm_dw_shift(self, X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift=-1):
-        self._side(lambda: self._timed('dW GEMM (conv_gemm_tn2)', 2.0 * M * K * N,
-                                       lambda: lib.taco_gemm_tn_shift(X, dY, dW, M, T, K, N, ldx, lddy, ldw, shift, self.st)))
+        self._side(('dw', X, dY, dW, M, T, K, N, 1, 0, ldx, lddy, ldw, shift, 2.0 * M * K * N))
 
     def colsum(self, x, out, M, C, ldx=None):
-        self._side(lambda: lib.taco_col_sum(x, ldx or x.stride(-2), out, M, C, self.st))
+        self._side(('cs', x, ldx or x.stride(-2), out, M, C))
 
     def dense_fwd(self, x, scope, y, M, cin, cout, act=0):
         self.gemm(x, self.P(scope + '/kernel'), self.P(scope + '/bias'), y, M, cin, cout, act=act)
@@ -393,6 +456,7 @@ class Engine:
         self.inputs, self.input_lengths, self.mel_targets, self.identities = inputs, input_lengths, mel_targets, identities
         E = L.Et + L.Es
         Me, Mp, Ms = N * Ti, N * To, N * S
+        self._mark('start')
         X0 = self.buf('emb', Me, E)
         lib.taco_embed_gather_fwd(inputs, identities if L.Es else None, self.P('embedding'),
                                   self.P('embedding_id') if L.Es else None, X0, N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
@@ -400,6 +464,7 @@ class Engine:
         self.dense_fwd(X0, 'prenet/dense_1', A1, Me, E, 256, ACT_RELU)
         self.dense_fwd(A1, 'prenet/dense_2', A2, Me, 256, 128, ACT_RELU)
         ENC = self.cbhg_fwd('encoder_cbhg', A2, N, Ti, 128, 16, (128, 128), input_lengths, training)
+        self._mark('encoder fwd')
         # ---- decoder
         KEYS = self.buf('keys', Me, 256)
         self.gemm(ENC, self.P('attention/memory_layer/kernel'), None, KEYS, Me, 256, 256)
@@ -449,9 +514,11 @@ class Engine:
         prev = gb[2]['D']
         MEL = self.buf('mel_out', N, To, nm)             # == decoder outputs [N,S,nm*r] (tacotron.py:97)
         self.dense_fwd(prev, 'output_projection', MEL.view(Ms, nm * r), Ms, 256, nm * r)
+        self._mark('decoder fwd')
         POST = self.cbhg_fwd('post_cbhg', MEL.view(Mp, nm), N, To, nm, 8, (256, nm), None, training)
         LIN = self.buf('lin_out', N, To, self.nf)
         self.gemm(POST, self.P('linear/kernel'), self.P('linear/bias'), LIN, Mp, 256, self.nf, ldw=L.ld_lin, ldy=self.nf)
+        self._mark('post-net fwd')
         self.mel_outputs, self.linear_outputs = MEL, LIN
         self.alignments = self._bufs['ALIGN'].view(N, S, Ti).transpose(1, 2)      # [N, Ti, S] (tacotron.py:104)
         self.encoder_outputs = ENC.view(N, Ti, 256)
@@ -474,6 +541,14 @@ class Engine:
         k = k or self.pipe_chunks
         if k <= 1 or S < 2 * k or self.no_cluster or not lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti):
             return [(0, S)]
+        plan = os.environ.get('TACO_CHUNK_PLAN', '')
+        if plan:                                       # explicit relative chunk lengths, e.g. "40,36,28,16,8" (tuning aid)
+            w = [float(x) for x in plan.split(':')]
+            cuts = [0]
+            for x in w[:-1]:
+                cuts.append(min(S, max(cuts[-1] + 1, int(round(cuts[-1] + S * x / sum(w))))))
+            cuts.append(S)
+            return [(cuts[i], cuts[i + 1]) for i in range(len(w)) if cuts[i + 1] > cuts[i]]
         # The last chunk is half as long as the others: GRU1/GRU2 of the last chunk run after the attention recurrence has
         # finished (forward), and GRU2/GRU1 of the last chunk run before the attention BPTT can start (backward).
         last = max(1, int(S * self.last_chunk_frac / k))
@@ -667,6 +742,7 @@ class Engine:
         r, nm = self.r, self.nm
         Me, Mp, Ms = N * Ti, N * To, N * S
         E = L.Et + L.Es
+        self._mark('loss')
         self.grads.zero_()
         self._side_active = self.overlap_wgrad
         if self.world > 1:
@@ -683,9 +759,11 @@ class Engine:
         dPOST = self.buf('dpost', Mp, 256)
         self.gemm_dx(dLIN, self.P('linear/kernel'), dPOST, Mp, 256, L.ld_lin, ldw=L.ld_lin)
         dMELp = self.buf('dmel_post', Mp, nm)
-        self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, dMELp)
+        self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, dMELp,
+                      eager=os.environ.get('TACO_POST_EAGER', '0') == '1')
         if nb >= 2:
             self._bucket_ready(0)                       # post-net + linear
+        self._mark('post-net bwd')
         dOUT = self.buf('dout', Ms, nm * r)
         lib.taco_add(dMELp, b['dmel_loss'], dOUT, Mp * nm, 0, st)
         # output projection
@@ -716,11 +794,14 @@ class Engine:
                 R, U, C, RH, Hh = (b['g1_%s' % k] for k in ('r', 'u', 'c', 'rh', 'h'))
                 self.gru256_bwd(dD, self.P('decoder_gru_1/whg'), self.P('decoder_gru_1/whc'), R, U, C, Hh, dxp[1], car[1], xg[1],
                                 N, S, s0, s1)
+                # the projections into the attention BPTT's input stay on THIS stream: queued on the attention stream they would
+                # wait behind the previous (longer) attention chunk although their inputs are ready, and sit between two
+                # attention chunks on the critical path (57 + 68 + 199 us at C2)
+                self.dense_rows_dx(dxp[1], self.P('decoder_gru_1/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dY = dD1 + dxp1.Wx1^T
+                self.dense_rows_dx(dD, Wp, dHC, N, S, s0, s1, 512, 256, 256, 512, 0)                               # d[h|ctx] = dY.Wp^T
                 ev2 = torch.cuda.Event(); ev2.record(sb)
             sc_.wait_event(ev2)
             with torch.cuda.stream(sc_):
-                self.dense_rows_dx(dxp[1], self.P('decoder_gru_1/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dY = dD1 + dxp1.Wx1^T
-                self.dense_rows_dx(dD, Wp, dHC, N, S, s0, s1, 512, 256, 256, 512, 0)                               # d[h|ctx] = dY.Wp^T
                 for nb, tab in self._attn_ptrs:
                     self._timed('attention recurrence bwd (attn_cluster_bwd_k)', 2 * self._attn_flops(nb, Ti, s1 - s0),
                                 lambda: lib.taco_attn_rnn_bwd(tab, self._dims(nb, S, Ti, s0, s1), self.st))
@@ -730,6 +811,7 @@ class Engine:
                 self.flush_side()
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
+        self._mark('decoder bwd')
         dY = dD
         # weight gradients of the decoder (deferred to the side stream)
         for g in (2, 1):
@@ -775,6 +857,7 @@ class Engine:
                                    self.G('embedding_id') if L.Es else None,
                                    self.gnorm2 if (self.tf_sparse_norm and self.world == 1) else None,
                                    N, Ti, L.Et, L.Es, L.vocab, max(L.id_num, 1), st)
+        self._mark('encoder bwd')
         if nb:
             self._bucket_ready(nb - 1)                  # embeddings, encoder prenet, conv bank, proj_1: the tail of backward
         if self._side_active:
@@ -782,6 +865,7 @@ class Engine:
             for ss in self.side_streams:
                 torch.cuda.current_stream().wait_stream(ss)                # join: all weight gradients are complete
             self._side_active = False
+        self._mark('side-stream join')
 
     # ---- optimizer (models/tacotron.py:174-202) ---------------------------------------------------------------------------
     def optimizer_step(self):
@@ -802,6 +886,7 @@ class Engine:
             lib.taco_bn_ema(self.bn, self.bnbatch, L.bn_total, BN_MOMENTUM, self.global_step, self.err, st)   # UPDATE_OPS (tacotron.py:193) + step counter
         else:
             lib.taco_step_inc(self.global_step, self.err, st)
+        self._mark('optimizer')
 
     def allreduce_grads(self):
         """Data parallel exchange step (net-new): completes the bucketed RCCL all-reduce(sum) of the flat
@@ -816,6 +901,17 @@ class Engine:
                 self.exposed_events.append((e0, e1))
 
     def train_step(self, inputs, input_lengths, mel_targets, linear_targets, identities=None):
+        if self.main_stream is not None and not torch.cuda.is_current_stream_capturing():
+            # run the step on the engine's own (high-priority) stream, ordered after / before the caller's stream
+            outer = torch.cuda.current_stream()
+            self.main_stream.wait_stream(outer)
+            with torch.cuda.stream(self.main_stream):
+                self._train_step(inputs, input_lengths, mel_targets, linear_targets, identities)
+            outer.wait_stream(self.main_stream)
+        else:
+            self._train_step(inputs, input_lengths, mel_targets, linear_targets, identities)
+
+    def _train_step(self, inputs, input_lengths, mel_targets, linear_targets, identities=None):
         self.forward(inputs, input_lengths, mel_targets, identities, training=True)
         self.loss(linear_targets)
         self.backward()

@@ -382,6 +382,67 @@ def test_conv_bank(N, T, cin, K):
     assert rel(dw.cpu().numpy(), torch.cat([w.grad for w in w64], 0).cpu().numpy()) < 1e-5
 
 
+def test_grouped_weight_and_bias_gradients():
+    """taco_wgrad_group / taco_col_sum_group: many independent weight-gradient problems (dense, conv k=3, conv bank, shifted
+    recurrent-weight form, ragged shapes) in ONE launch against float64 references; more problems than one group holds."""
+    import ctypes
+    from tacotron_multispeaker_amd._lib import lib, stream
+    from tacotron_multispeaker_amd.engine import TacoWgrad, TacoColSum
+    dev = 'cuda'
+    torch.manual_seed(11)
+    probs = []          # (X, dY, dW, M, T, Cin, Cout, kw, bank, shift, reference)
+    def add(M, T, cin, cout, kw=1, bank=0, shift=0):
+        C = bank * 128 if bank else cout
+        x = torch.randn(M, cin, device=dev)
+        dy = torch.randn(M, C, device=dev)
+        taps = bank * (bank + 1) // 2 if bank else kw
+        dw = torch.zeros(taps, cin, 128 if bank else cout, device=dev)
+        x64, dy64 = x.double(), dy.double()
+        N = M // T
+        xs = x64.view(N, T, cin)
+        ref = torch.zeros_like(dw, dtype=torch.float64)
+        widths = range(1, bank + 1) if bank else [kw]
+        ti = 0
+        for k in widths:
+            d = dy64.view(N, T, -1)[:, :, (k - 1) * 128:k * 128] if bank else dy64.view(N, T, cout)
+            for j in range(k):
+                sh = j - (k - 1) // 2 + shift
+                xsft = torch.zeros_like(xs)
+                if sh >= 0:
+                    xsft[:, :T - sh] = xs[:, sh:]
+                else:
+                    xsft[:, -sh:] = xs[:, :T + sh]
+                ref[ti] = torch.einsum('ntc,ntd->cd', xsft, d)
+                ti += 1
+        probs.append((x, dy, dw, M, T, cin, 128 if bank else cout, 1 if bank else kw, bank, shift, ref))
+    add(4096, 4096, 128, 256)
+    add(640, 64, 256, 80, kw=3)
+    add(384, 48, 128, 0, bank=16)
+    add(512, 64, 256, 512, shift=-1)
+    add(330, 33, 20, 36, kw=5)
+    add(2048, 128, 1024, 128, kw=3)
+    for i in range(30):
+        add(256 + 64 * (i % 5), 32, 64 + 4 * i, 128 + 4 * (i % 7))
+    arr = (TacoWgrad * len(probs))()
+    for a, (x, dy, dw, M, T, cin, cout, kw, bank, shift, _) in zip(arr, probs):
+        a.X, a.dY, a.dW = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+        a.M, a.T, a.Cin, a.Cout, a.kw, a.bank_K, a.ldx, a.lddy, a.ldw, a.shift = M, T, cin, cout, kw, bank, cin, dy.shape[1], cout, shift
+    lib.taco_wgrad_group(ctypes.addressof(arr), len(probs), stream())
+    torch.cuda.synchronize()
+    for (x, dy, dw, M, T, cin, cout, kw, bank, shift, ref) in probs:
+        assert rel(dw.cpu().numpy(), ref.cpu().numpy()) < 1e-5, (M, T, cin, cout, kw, bank, shift)
+    cs = (TacoColSum * len(probs))()
+    outs = []
+    for a, (x, dy, *_r) in zip(cs, probs):
+        o = torch.zeros(dy.shape[1], device=dev)
+        outs.append(o)
+        a.x, a.out, a.ldx, a.M, a.C = dy.data_ptr(), o.data_ptr(), dy.shape[1], dy.shape[0], dy.shape[1]
+    lib.taco_col_sum_group(ctypes.addressof(cs), len(probs), stream())
+    torch.cuda.synchronize()
+    for o, (x, dy, *_r) in zip(outs, probs):
+        assert rel(o.cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-5
+
+
 def test_empty_and_invalid_arguments_are_rejected():
     from tacotron_multispeaker_amd._lib import lib, stream
     x = torch.zeros(16, 8, device='cuda')
