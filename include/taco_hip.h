@@ -167,6 +167,8 @@ int taco_adam_step(float* params, const float* grads, float* m, float* v, long n
 int taco_bn_ema(float* moving, const float* batch, int n, float momentum, int* global_step, const int* err, hipStream_t stream);
 int taco_step_inc(int* global_step, const int* err, hipStream_t stream);
 int taco_scale(float* x, long n, float s, hipStream_t stream);
+/* zero-fill (one memset node): bytes and p must be multiples of 16 */
+int taco_zero(void* p, size_t bytes, hipStream_t stream);
 
 /* pointer-table slots of taco_attn_rnn_fwd / taco_attn_rnn_bwd (all fp32 device pointers) */
 enum TacoAttnPtr {

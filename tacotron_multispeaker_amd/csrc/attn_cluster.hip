@@ -47,8 +47,8 @@ __device__ __forceinline__ void put_gi(u64* base, unsigned idx, unsigned epoch, 
     put_g(base + idx, epoch, v, local);
 }
 // placement check of one cluster, broadcast to the workgroup (flag_l: an LDS int)
-__device__ __forceinline__ bool cluster_local(u64* slots, int w, int* err, int* flag_l, int tid, int allow) {
-    return cluster_shares_xcd(slots, w, CW, err, flag_l, tid, allow);
+__device__ __forceinline__ bool cluster_local(u64* slots, int w, int* err, int* flag_l, int tid, int allow, unsigned salt) {
+    return cluster_shares_xcd(slots, w, CW, err, flag_l, tid, allow, salt);
 }
 // TACO_XCD_LOCAL=0 keeps the agent-scope form everywhere (A/B timing, tests of the placement-independent path)
 static int xcd_local_allowed() { const char* e = getenv("TACO_XCD_LOCAL"); return (e && e[0] == '0') ? 0 : 1; }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     const long per_clu = 2 * 256 * 4 + 2 * 128 + (long)CW * 2 * Ti;
     u64* X = p.xchg + (long)cl * per_clu;
     u64 *xCTX = X, *xP1 = X + 512, *xP2 = X + 1024, *xRH = X + 1280, *xH = X + 1792, *xE = X + 2304;
-    const bool local = cluster_local(p.xchg + (long)nclus * per_clu + (long)cl * CW, w, p.err, reinterpret_cast<int*>(cp_l), tid, p.xcd_local);
+    const bool local = cluster_local(p.xchg + (long)nclus * per_clu + (long)cl * CW, w, p.err, reinterpret_cast<int*>(cp_l), tid, p.xcd_local, (unsigned)p.s0);
     float fnx0 = 0.f, fnx1 = 0.f;
     if (pA == 0) {
         fnx0 = p.f1[(unsigned)(rw[0] * S + p.s0) * 256u + 32 * w + cA];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     else dot2<32>(h_l, h_l + PLEN(256), pC * 32, wgh, gh0, gh1);
 
     for (int s = p.s0; s < p.s1; ++s) {
-        const unsigned epoch = (unsigned)(s - p.s0) + 1;
+        const unsigned epoch = (unsigned)s + 1;          // step of the PASS: the chunk launches of a pass share one zero-filled buffer
         STAMP(0);
         unsigned so0 = (unsigned)(rw[0] * S + s), so1 = (unsigned)(rw[1] * S + s);   // row offsets into [N,S,*] tensors
         asm volatile("" : "+v"(so0), "+v"(so1));      // opaque: addresses are formed at the point of use (see above)
@@ -465,7 +465,9 @@ int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
             return TACO_EINVAL;
         attr_set = true;
     }
-    if (hipMemsetAsync(p.xchg, 0, (size_t)(taco_attn_cluster_xchg_slots(p.N, p.Ti) - 16) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    // granule epochs count the steps of the whole pass, so only the pass's first chunk launch needs a zero-filled buffer
+    if (p.s0 == 0 && hipMemsetAsync(p.xchg, 0, (size_t)(taco_attn_cluster_xchg_slots(p.N, p.Ti) - 16) * sizeof(u64), st) != hipSuccess)
+        return TACO_EINVAL;
     AttnClu q = p;
     q.xcd_local = xcd_local_allowed();
     if (taco_attn_cluster_fwd_variant(p.N, p.Ti) == 1)
@@ -594,7 +596,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     const long per_clu = (long)CW * 2 * Ti + 2 * 256 * 5 + 2 * 128;
     u64* X = p.xchg + (long)cl * per_clu;
     u64 *xDQ = X, *xDCP = X + 512, *xDGR = X + 1024, *xDGU = X + 1536, *xDP2 = X + 2048, *xDP1 = X + 2304, *xDA = X + 2816;
-    const bool local = cluster_local(p.xchg + (long)nclus * per_clu + (long)cl * CW, w, p.err, reinterpret_cast<int*>(cp_l), tid, p.xcd_local);
+    const bool local = cluster_local(p.xchg + (long)nclus * per_clu + (long)cl * CW, w, p.err, reinterpret_cast<int*>(cp_l), tid, p.xcd_local,
+                                     (unsigned)(p.S - p.s1));
 
     float dhc0 = 0.f, dhc1 = 0.f;      // dh carry   (owner lanes: pA == 0, index jA)
     float dcc0 = 0.f, dcc1 = 0.f;      // dctx carry (owner lanes: pA == 0, index jA)
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         const int tid = tq;
         const int cA = tid >> 4, pA = tid & 15, cB = tid >> 5, pB = tid & 31;
         const int jA = 32 * w + cA, jB = 16 * w + cB;
-        const unsigned epoch = (unsigned)(p.s1 - s);
+        const unsigned epoch = (unsigned)(S - s);        // step of the PASS (descending s): see the forward kernel
         unsigned so[2] = {(unsigned)(rw[0] * S + s), (unsigned)(rw[1] * S + s)};
         asm volatile("" : "+v"(so[0]), "+v"(so[1]));   // opaque per-step offsets: no precomputed 64-bit addresses kept live
         // ---- this step's saved activations / external gradients were fetched ONE STEP AHEAD (registers), so their HBM
@@ -905,7 +908,8 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
         attr_set = true;
     }
     if (attn_cluster_bwd_smem(p.Ti, false) > 160 * 1024) return TACO_EINVAL;
-    if (hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;
+    if (p.s1 == p.S && hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess)
+        return TACO_EINVAL;
     AttnCluB q = p;
     q.xcd_local = xcd_local_allowed();
     if (taco_attn_cluster_bwd_variant(p.N, p.Ti) == 1)

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
     u64* xr = p.xchg + ((long)cl * 2) * HD;                               // rh granules  [2][256]
     u64* xh = p.xchg + ((long)nclus * 2 + (long)cl * 2) * HD;             // h' granules
     __shared__ int local_s;
-    const bool local = cluster_shares_xcd(p.xchg + (long)nclus * 4 * HD + (long)cl * 4, w, 4, p.err, &local_s, tid, p.xcd_local);
+    const bool local = cluster_shares_xcd(p.xchg + (long)nclus * 4 * HD + (long)cl * 4, w, 4, p.err, &local_s, tid, p.xcd_local, (unsigned)p.s0);
     const int j_own = 64 * w + (gcol & 63);                               // hidden index of this thread's gate column
     const int jc = 64 * w + ccol;                                         // hidden index of the candidate column
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_fwd_k(Gru256 p) {
     if (k8 == 0) { nxc0 = p.xp[(rb0 + p.s0) * 768u + 512u + jc]; nxc1 = p.xp[(rb1 + p.s0) * 768u + 512u + jc]; }
 
     for (int s = p.s0; s < p.s1; ++s) {
-        const unsigned epoch = (unsigned)(s - p.s0) + 1;
+        const unsigned epoch = (unsigned)s + 1;          // step of the PASS: the chunk launches of a pass share one zero-filled buffer
         unsigned o0 = rb0 + s, o1 = rb1 + s;
         asm volatile("" : "+v"(o0), "+v"(o1));           // opaque: store addresses are formed at the point of use
         const float xg0 = nxg0, xg1 = nxg1, xc0 = nxc0, xc1 = nxc1;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
     u64* xgr = p.xchg + ((long)nclus * 2) * HD + ((long)cl * 2) * HD;        // dg_r granules [2][256]
     u64* xgu = p.xchg + ((long)nclus * 4) * HD + ((long)cl * 2) * HD;        // dg_u granules [2][256]
     __shared__ int local_s;
-    const bool local = cluster_shares_xcd(p.xchg + (long)nclus * 6 * HD + (long)cl * 4, w, 4, p.err, &local_s, tid, p.xcd_local);
+    const bool local = cluster_shares_xcd(p.xchg + (long)nclus * 6 * HD + (long)cl * 4, w, 4, p.err, &local_s, tid, p.xcd_local, (unsigned)(p.S - p.s1));
     const bool owner = j8 == 0;
 
     float dhT[2] = {0.f, 0.f}, dhn[2] = {0.f, 0.f};
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
     }
 
     for (int s = p.s1 - 1; s >= p.s0; --s) {
-        const unsigned epoch = (unsigned)(p.s1 - s);
+        const unsigned epoch = (unsigned)(p.S - s);
         unsigned o[2] = {rb[0] + s, rb[1] + s};
         asm volatile("" : "+v"(o[0]), "+v"(o[1]));
         float r_[2], u_[2], c_[2], hp_[2], don[2], du[2] = {0.f, 0.f}, dhd[2] = {0.f, 0.f};
@@ -369,7 +369,8 @@ extern "C" int taco_gru256_seq_fwd(const float* xp, const float* whg, const floa
     if (d && !res) return TACO_EINVAL;
     if (gru256_grid(N) > 256) return TACO_EINVAL;           // all workgroups must be co-resident
     const int nclus = (N + 1) / 2;
-    if (hipMemsetAsync(xchg, 0, (size_t)nclus * (2 * 2 * HD + 4) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;     // + placement granules
+    // granule epochs count the steps of the whole pass: only the pass's first chunk launch needs a zero-filled buffer
+    if (s0 == 0 && hipMemsetAsync(xchg, 0, (size_t)nclus * (2 * 2 * HD + 4) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;     // + placement granules
     Gru256 p{};
     p.xp = xp; p.whg = whg; p.whc = whc; p.res = res; p.r = r; p.u = u; p.c = c; p.rh = rh; p.h = h; p.d = d;
     p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1; p.xcd_local = gru_xcd_local_allowed();
@@ -384,7 +385,7 @@ extern "C" int taco_gru256_seq_bwd(const float* dout, const float* whg, const fl
     if (s0 < 0 || s1 > S || s0 >= s1) return TACO_EINVAL;
     if (gru256_grid(N) > 256) return TACO_EINVAL;
     const int nclus = (N + 1) / 2;
-    if (hipMemsetAsync(xchg, 0, (size_t)nclus * (2 * 3 * HD + 4) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;     // + placement granules
+    if (s1 == S && hipMemsetAsync(xchg, 0, (size_t)nclus * (2 * 3 * HD + 4) * sizeof(u64), st) != hipSuccess) return TACO_EINVAL;     // + placement granules
     Gru256 p{};
     p.dout = dout; p.whg = whg; p.whc = whc; p.r = const_cast<float*>(r); p.u = const_cast<float*>(u);
     p.c = const_cast<float*>(c); p.h = const_cast<float*>(h); p.dxp = dxp;

@@ -109,6 +109,13 @@ extern "C" int taco_step_inc(int* global_step, const int* err, hipStream_t strea
     TACO_RETURN_LAST();
 }
 
+// one memset node (graph capturable) for the buffers that must start a step at zero: gradients + reduction scratch
+extern "C" int taco_zero(void* p, size_t bytes, hipStream_t stream) {
+    if (!p || (bytes & 15) || (reinterpret_cast<uintptr_t>(p) & 15)) return TACO_EINVAL;
+    if (bytes && hipMemsetAsync(p, 0, bytes, stream) != hipSuccess) return TACO_EINVAL;
+    return TACO_OK;
+}
+
 extern "C" int taco_scale(float* x, long n, float s, hipStream_t stream) {
     if (n & 3) return TACO_EINVAL;
     long g = (n / 4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;

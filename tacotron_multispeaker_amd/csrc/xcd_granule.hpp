@@ -27,22 +27,26 @@ __device__ __forceinline__ unsigned xcc_id() {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
     return x;
 }
-#define TACO_XCD_TAG 0x58434431u     // 'XCD1': epoch of the placement granules (step epochs start at 1 and stay far below)
+#define TACO_XCD_TAG 0x58430000u     // 'XC..': epochs of the placement granules = this + the launch's first step (step epochs stay far below)
 #define TACO_XCD_SPIN (1 << 22)
 // Workgroup-wide form: lane i < cw polls member i's placement granule; the verdict is broadcast through the LDS int *flag_l.
 // Contains two workgroup barriers: every thread of the workgroup must call it.  allow = 0 skips the exchange (agent scope).
-__device__ __forceinline__ bool cluster_shares_xcd(u64* slots, int w, int cw, int* err, int* flag_l, int tid, int allow) {
+// salt: distinguishes the launches that share one zero-filled granule buffer (the chunk launches of one recurrence pass: the
+// chunk's first step), so a placement granule of an earlier launch is never taken for this launch's.
+__device__ __forceinline__ bool cluster_shares_xcd(u64* slots, int w, int cw, int* err, int* flag_l, int tid, int allow,
+                                                   unsigned salt = 0) {
     if (tid == 0) *flag_l = allow ? 1 : 0;
     __syncthreads();
     if (allow && tid < cw) {
         const unsigned mine = xcc_id();
-        if (tid == 0) __hip_atomic_store(slots + w, ((u64)TACO_XCD_TAG << 32) | (u64)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tag = TACO_XCD_TAG + salt;
+        if (tid == 0) __hip_atomic_store(slots + w, ((u64)tag << 32) | (u64)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u64 x;
         int spins = 0;
         bool ok = true;
         for (;;) {
             x = __hip_atomic_load(slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(x >> 32) == TACO_XCD_TAG) break;
+            if ((unsigned)(x >> 32) == tag) break;
             if (++spins > TACO_XCD_SPIN) { if (err) atomicExch(err, 1); ok = false; break; }
         }
         if (!ok || (unsigned)x != mine) *flag_l = 0;

@@ -89,13 +89,17 @@ class Engine:
         self.regularity = dict(overwrought=0.0, oneorder_dynamic=0.0, variance_between_row=0.0, alignment_entropy=0.0)
         f = dict(dtype=torch.float32, device=self.dev)
         self.params = torch.zeros(L.total, **f)
-        self.grads = torch.zeros(L.total, **f)
+        # gradients and the per-step reduction scratch (doubles: BN sums, loss sums, norms) share ONE allocation that a single
+        # memset node zero-fills at the start of a step (forward)
+        self._zero_doubles = 1 << 18
+        self._zbuf = torch.zeros(L.total * 4 + self._zero_doubles * 8, dtype=torch.uint8, device=self.dev)
+        self.grads = self._zbuf[:L.total * 4].view(torch.float32)
         self.m = torch.zeros(L.total, **f)
         self.v = torch.zeros(L.total, **f)
         self.bn = torch.zeros(max(L.bn_total, 4), **f)              # moving mean / variance
         self.bnbatch = torch.zeros(max(L.bn_total, 4), **f)         # batch mean / variance of the last step
         self.global_step = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.dscratch = torch.zeros(1 << 18, dtype=torch.float64, device=self.dev)   # zeroed once per step
+        self.dscratch = self._zbuf[L.total * 4:].view(torch.float64)                 # zeroed once per step
         self.info = torch.zeros(4, **f)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._bufs = {}
@@ -452,7 +456,7 @@ class Engine:
         S = To // r
         self.dims = (N, Ti, To, S)
         self._dpos = 0
-        self.dscratch.zero_()
+        lib.taco_zero(self._zbuf, self._zbuf.numel(), st)      # gradients + reduction scratch: one memset node
         self.inputs, self.input_lengths, self.mel_targets, self.identities = inputs, input_lengths, mel_targets, identities
         E = L.Et + L.Es
         Me, Mp, Ms = N * Ti, N * To, N * S
@@ -481,7 +485,7 @@ class Engine:
         for g in (1, 2):
             gb[g] = dict(XP=self.buf('xp%d' % g, Ms, 768), D=self.buf('D%d' % g, Ms, 256),
                          t=[self.buf('g%d_%s' % (g, k), Ms, 256) for k in ('r', 'u', 'c', 'rh', 'h')],
-                         x=self.buf('xchg_g%d' % g, ((N + 1) // 2) * 16 * 256, dtype=torch.int64))
+                         x=self.buf('xchg_g%d' % g, ((N + self.GRU256_ROWS - 1) // self.GRU256_ROWS) * self.GRU256_XCHG, dtype=torch.int64))
         # Chunk-pipelined decoder: attention recurrence on the current stream, GRU1 / GRU2 on two more streams; chunk c
         # of GRU1 (its hoisted projections first) starts as soon as the attention kernel has finished chunk c.
         chunks = self._chunks(N, S, Ti)
@@ -570,21 +574,27 @@ class Engine:
     GRU256_ROWS = 128
     ATTN_ROWS = 64
 
+    GRU256_XCHG = 64 * 2048        # granule slots of one GRU(256) row block (>= 64 clusters x (6 x 256 + 4))
+
     def gru256_fwd(self, xp, whg, whc, res, t, d, xchg, N, S, s0, s1):
-        for n0 in range(0, N, self.GRU256_ROWS):
+        # every row block has its own granule region: the chunk launches of a pass share a buffer that is zero-filled once,
+        # by the pass's first launch (epochs count the steps of the pass)
+        for bi, n0 in enumerate(range(0, N, self.GRU256_ROWS)):
             n1 = min(N, n0 + self.GRU256_ROWS)
             v = lambda a, w: a.view(N, S * w)[n0:n1]
+            xchg_b = xchg[bi * self.GRU256_XCHG:]
             self._timed('decoder GRU(256) fwd (gru256_cluster_fwd_k)', (s1 - s0) * 2.0 * (n1 - n0) * 256 * 768,
                         lambda: lib.taco_gru256_seq_fwd(v(xp, 768), whg, whc, v(res, 256), v(t[0], 256), v(t[1], 256), v(t[2], 256),
-                                                        v(t[3], 256), v(t[4], 256), v(d, 256), xchg, self.err, n1 - n0, S, s0, s1, self.st))
+                                                        v(t[3], 256), v(t[4], 256), v(d, 256), xchg_b, self.err, n1 - n0, S, s0, s1, self.st))
 
     def gru256_bwd(self, dout, whg, whc, r, u, c, h, dxp, carry, xchg, N, S, s0, s1):
-        for n0 in range(0, N, self.GRU256_ROWS):
+        for bi, n0 in enumerate(range(0, N, self.GRU256_ROWS)):
             n1 = min(N, n0 + self.GRU256_ROWS)
             v = lambda a, w: a.view(N, S * w)[n0:n1]
+            xchg_b = xchg[bi * self.GRU256_XCHG:]
             self._timed('decoder GRU(256) bwd (gru256_cluster_bwd_k)', (s1 - s0) * 2.0 * (n1 - n0) * 256 * 768,
                         lambda: lib.taco_gru256_seq_bwd(v(dout, 256), whg, whc, v(r, 256), v(u, 256), v(c, 256), v(h, 256), v(dxp, 768),
-                                                        carry.view(N, 256)[n0:n1], xchg, self.err, n1 - n0, S, s0, s1, self.st))
+                                                        carry.view(N, 256)[n0:n1], xchg_b, self.err, n1 - n0, S, s0, s1, self.st))
 
     def dense_rows(self, x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, ldy):
         lib.taco_dense_rows_fwd(x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, cout, ldy, 0, 0, self.st)
@@ -674,7 +684,8 @@ class Engine:
             'DVPART': b('dVPART', N * Ti, 256), 'DA': b('dA', N * Ti), 'DHT': b('dHT', N, 256),
             'DHPART': b('dHPART', N, 256), 'DHCARRY': b('dHCARRY', N, 256), 'DCTX': b('dCTX', N, 256),
             'DCTXCARRY': b('dCTXCARRY', N, 256),
-            'XCHG': None if self.no_cluster else b('xchg_attn', max(self._attn_slots(N, Ti), 8), dtype=torch.int64), 'ERR': self.err,
+            'XCHG': None if self.no_cluster else b('xchg_attn', max(self._attn_slots(min(N, self.ATTN_ROWS), Ti), 8) *
+                                                   ((N + self.ATTN_ROWS - 1) // self.ATTN_ROWS), dtype=torch.int64), 'ERR': self.err,
             'DE': b('dE', N * S, Ti), 'DCTXS': b('dCTXS', N * S, 256),
             'DAEXT': b('dALIGN_reg', N * S, Ti) if self.has_regularity else None,
         }
@@ -688,10 +699,13 @@ class Engine:
         # take any N: one table.)
         blk = self.ATTN_ROWS if (not self.no_cluster and lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti)) else N
         tables = []
-        for n0 in range(0, N, blk):
+        xslots = max(self._attn_slots(min(N, self.ATTN_ROWS), Ti), 8) if not self.no_cluster else 0
+        for bi, n0 in enumerate(range(0, N, blk)):
             n1 = min(N, n0 + blk)
             arr = (ctypes.c_void_p * len(_AP))(*[(t[n].data_ptr() + 4 * n0 * row.get(n, 0)) if t[n] is not None else None
                                                 for n in _AP])
+            if t['XCHG'] is not None:          # own granule region per row block (zero-filled once per pass, see gru256_fwd)
+                arr[AP['XCHG']] = t['XCHG'].data_ptr() + 8 * bi * xslots
             tables.append((n1 - n0, arr))
         self._attn_keep = t
         return tables
@@ -743,8 +757,7 @@ class Engine:
         Me, Mp, Ms = N * Ti, N * To, N * S
         E = L.Et + L.Es
         self._mark('loss')
-        self.grads.zero_()
-        self._side_active = self.overlap_wgrad
+        self._side_active = self.overlap_wgrad          # (the gradient buffer was zero-filled at the start of forward)
         if self.world > 1:
             from . import dp
             if self._exchange is None:
@@ -776,8 +789,9 @@ class Engine:
         cur = torch.cuda.current_stream()
         sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
         dHC = b['dHC']
-        for k in ('dQ', 'dKEYS', 'dMEM', 'dVPART'):
-            b[k].zero_()
+        if self.no_cluster or not lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti):
+            for k in ('dQ', 'dKEYS', 'dMEM', 'dVPART'):     # accumulators of the per-step kernels; the cluster path writes them
+                lib.taco_zero(b[k], b[k].numel() * 4, st)
         dxp = {g: self.buf('dxp%d' % g, Ms, 768) for g in (1, 2)}
         car = {g: self.buf('gcarry%d' % g, N, 256) for g in (1, 2)}
         xg = {g: b['xchg_g%d' % g] for g in (1, 2)}
