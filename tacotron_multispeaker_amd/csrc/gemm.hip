@@ -849,8 +849,11 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int c0 = bx * BM, n0 = by * BN;
-    int seg = bz / p.splitk;
-    const int split = bz - seg * p.splitk;
+    // bz = split * nseg + segment: the (conv width, tap) segments of one row range are neighbours in the tile order, so the row
+    // range's X and dY tiles are re-read from L2 for every tap instead of from memory (conv bank: sum k = 36 / 136 taps)
+    const int nseg = p.bank ? p.kw_hi * (p.kw_hi + 1) / 2 : p.kw_lo;
+    const int split = bz / nseg;
+    int seg = bz - split * nseg;
     int kw = p.kw_lo, j = seg;
     if (p.bank) { kw = 1; while (seg >= kw) { seg -= kw; ++kw; } j = seg; }
     const int shift = j - (kw - 1) / 2 + p.shift0;
@@ -984,7 +987,16 @@ __global__ __launch_bounds__(256) void conv_gemm_tn2_group(WgradGroup g) {
     const int b = blockIdx.x;
     int i = 0;
     while (i + 1 < g.count && b >= g.first[i + 1]) ++i;      // wave-uniform scan of <= 32 kernel-argument words
-    const int r = b - g.first[i], gx = g.gx[i], gy = g.gy[i];
+    const int first = g.first[i], end = g.first[i + 1], gx = g.gx[i], gy = g.gy[i];
+    // XCD-aware tile order inside a problem: the workgroups that land on one XCD (global index mod 8 under round-robin placement;
+    // speed only) take a CONTIGUOUS run of the problem's tiles, ordered (row segment, dY column tile, X column tile): they share
+    // the dY tile and walk the X tiles of one row segment, so an operand is fetched into one L2 instead of all eight (rocprofv3
+    // FETCH_SIZE of the grouped launches before this remap: 315 MB per launch for ~55 MB of operands).  Bijective for any sizes.
+    auto upto = [](int n, int x) { return (n + 7 - x) >> 3; };       // blocks in [0, n) with index mod 8 == x
+    const int x = b & 7;
+    int base = 0;
+    for (int y = 0; y < x; ++y) base += upto(end, y) - upto(first, y);
+    const int r = base + upto(b, x) - upto(first, x);
     tn2_body<BM, BN, BK, STAGES>(g.p[i], r % gx, (r / gx) % gy, r / (gx * gy));
 }
 
