@@ -91,6 +91,14 @@ int taco_bn_bwd(const float* x, int ldx, const float* dy, int lddy, const float*
 /* ---- highway gating (models/modules.py:77-90); Z [M,256] = x.[W_H|W_T]+b in, [relu(H), sigmoid(T)] out -------- */
 int taco_highway_gate_fwd(float* Z, const float* x, float* y, int M, hipStream_t stream);
 int taco_highway_gate_bwd(const float* HT, const float* x, const float* dy, float* dZ, float* dx, int M, hipStream_t stream);
+/* the four highway layers of a CBHG in ONE launch per direction (csrc/highway.hip); W4 / b4 / Z4 / y4 ... are HOST arrays of four
+ * device pointers (layer 1..4).  forward: Z4[l] [M,256] <- [relu(H) | sigmoid(T)], y4[l] [M,128] <- layer outputs.
+ * backward: dy = gradient wrt y4[3]; HT4 = the saved Z4, xin4[l] = input of layer l (x0, y4[0..2]); dZ4[l] [M,256] <- gradient
+ * wrt the pre-activations (operand of the dW / bias gradients), dx [M,128] <- gradient wrt x0. */
+int taco_highway4_fwd(const float* x0, const float* const* W4, const float* const* b4, float* const* Z4, float* const* y4,
+                      int M, hipStream_t stream);
+int taco_highway4_bwd(const float* dy, const float* const* HT4, const float* const* xin4, const float* const* W4,
+                      float* const* dZ4, float* dx, int M, hipStream_t stream);
 int taco_relu_bwd(const float* y, const float* dy, float* dpre, long n, hipStream_t stream);
 int taco_add(const float* a, const float* b, float* y, long n, int accumulate, hipStream_t stream);
 

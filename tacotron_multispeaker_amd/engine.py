@@ -120,6 +120,7 @@ class Engine:
         self.last_chunk_frac = float(os.environ.get('TACO_LAST_CHUNK', '0.5'))     # last chunk length / (S / chunks)
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.group_wgrad = os.environ.get('TACO_GROUP_WGRAD', '1') != '0'      # grouped weight / bias gradient launches
+        self.fused_highway = os.environ.get('TACO_FUSED_HIGHWAY', '1') != '0'  # four highway layers in one launch per direction
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
         self.world = 1                 # data-parallel replicas (set by train.py / bench.py after init_process_group)
         self.comm_stream = torch.cuda.Stream(device=self.dev)    # bucket all-reduces are ordered behind this stream
@@ -370,12 +371,20 @@ class Engine:
         if proj[1] != 128:
             hw = self.buf(sc + '/hwd', M, 128)
             self.dense_fwd(HW0, sc + '/highway_dense', hw, M, proj[1], 128)
-        for i in range(1, 5):
-            Z = self.buf('%s/hwZ%d' % (sc, i), M, 256)
-            self.gemm(hw, self.P('%s/highway_%d/kernel' % (sc, i)), self.P('%s/highway_%d/bias' % (sc, i)), Z, M, 128, 256)
-            nxt = self.buf('%s/hw%d' % (sc, i), M, 128)
-            lib.taco_highway_gate_fwd(Z, hw, nxt, M, st)
-            hw = nxt
+        Zs = [self.buf('%s/hwZ%d' % (sc, i), M, 256) for i in range(1, 5)]
+        ys = [self.buf('%s/hw%d' % (sc, i), M, 128) for i in range(1, 5)]
+        if self.fused_highway:
+            # the four layers in one launch: the tile's activations stay in LDS, [W_H | W_T] streams through an LDS ring
+            pa = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+            self._timed('highway x4 fwd (highway4_fwd_k)', 4 * 2.0 * M * 128 * 256,
+                        lambda: lib.taco_highway4_fwd(hw, pa([self.P('%s/highway_%d/kernel' % (sc, i)) for i in range(1, 5)]),
+                                                      pa([self.P('%s/highway_%d/bias' % (sc, i)) for i in range(1, 5)]), pa(Zs), pa(ys), M, st))
+            hw = ys[3]
+        else:
+            for i in range(1, 5):
+                self.gemm(hw, self.P('%s/highway_%d/kernel' % (sc, i)), self.P('%s/highway_%d/bias' % (sc, i)), Zs[i - 1], M, 128, 256)
+                lib.taco_highway_gate_fwd(Zs[i - 1], hw, ys[i - 1], M, st)
+                hw = ys[i - 1]
         XP = self.buf(sc + '/xp', M, 768)
         self.gemm(hw, self.P(sc + '/bigru/wx'), self.P(sc + '/bigru/bias'), XP, M, 128, 768)
         OUT = self.buf(sc + '/out', M, 256)
@@ -409,15 +418,27 @@ class Engine:
         dhw = self.buf(sc + '/dhw_a', M, 128)
         self.gemm_dx(dXP, self.P(sc + '/bigru/wx'), dhw, M, 128, 768)
         other = self.buf(sc + '/dhw_b', M, 128)
-        for i in range(4, 0, -1):
-            dZ = self.buf('%s/dZ%d' % (sc, i), M, 256)      # one per layer: read later by the side-stream dW GEMM
-            hw_in = b['%s/hw%d' % (sc, i - 1)] if i > 1 else (b[sc + '/hwd'] if proj[1] != 128 else b[sc + '/hw0'])
-            lib.taco_highway_gate_bwd(b['%s/hwZ%d' % (sc, i)], hw_in, dhw, dZ, other, M, st)
-            self.gemm_dw(hw_in, dZ, self.G('%s/highway_%d/kernel' % (sc, i)), M, 128, 256)
-            self.colsum(dZ, self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
-            self.gemm_dx(dZ, self.P('%s/highway_%d/kernel' % (sc, i)), other, M, 128, 256, acc=1)
+        hw_ins = [(b[sc + '/hwd'] if proj[1] != 128 else b[sc + '/hw0'])] + [b['%s/hw%d' % (sc, i)] for i in range(1, 4)]
+        dZs = [self.buf('%s/dZ%d' % (sc, i), M, 256) for i in range(1, 5)]      # one per layer: read later by the side-stream dW GEMM
+        if self.fused_highway:
+            pa = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+            self._timed('highway x4 bwd (highway4_bwd_k)', 4 * 2.0 * M * 128 * 256,
+                        lambda: lib.taco_highway4_bwd(dhw, pa([b['%s/hwZ%d' % (sc, i)] for i in range(1, 5)]), pa(hw_ins),
+                                                      pa([self.P('%s/highway_%d/kernel' % (sc, i)) for i in range(1, 5)]), pa(dZs), other, M, st))
+            for i in range(4, 0, -1):
+                self.gemm_dw(hw_ins[i - 1], dZs[i - 1], self.G('%s/highway_%d/kernel' % (sc, i)), M, 128, 256)
+                self.colsum(dZs[i - 1], self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
             dhw, other = other, dhw
             flush()
+        else:
+            for i in range(4, 0, -1):
+                dZ, hw_in = dZs[i - 1], hw_ins[i - 1]
+                lib.taco_highway_gate_bwd(b['%s/hwZ%d' % (sc, i)], hw_in, dhw, dZ, other, M, st)
+                self.gemm_dw(hw_in, dZ, self.G('%s/highway_%d/kernel' % (sc, i)), M, 128, 256)
+                self.colsum(dZ, self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
+                self.gemm_dx(dZ, self.P('%s/highway_%d/kernel' % (sc, i)), other, M, 128, 256, acc=1)
+                dhw, other = other, dhw
+                flush()
         if proj[1] != 128:
             dHW0 = self.buf(sc + '/dhw0', M, proj[1])
             self.dense_bwd(b[sc + '/hw0'], dhw, sc + '/highway_dense', M, proj[1], 128, dx=dHW0)

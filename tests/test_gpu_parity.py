@@ -443,6 +443,53 @@ def test_grouped_weight_and_bias_gradients():
         assert rel(o.cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('M', [64, 200, 4096, 20480 + 17])
+def test_fused_highway_stack(M):
+    """taco_highway4_fwd / taco_highway4_bwd (csrc/highway.hip): four highway layers (reference models/modules.py:77-90) in one
+    launch per direction against a float64 torch composition: layer outputs, saved gate activations, the pre-activation
+    gradients dZ of every layer and the input gradient; ragged row counts."""
+    import ctypes
+    from tacotron_multispeaker_amd._lib import lib, stream
+    dev = 'cuda'
+    torch.manual_seed(M)
+    x0 = torch.randn(M, 128, device=dev)
+    W = [torch.randn(128, 256, device=dev) / np.sqrt(128) for _ in range(4)]
+    b = [torch.randn(256, device=dev) * 0.3 - torch.cat([torch.zeros(128), torch.ones(128)]).to(dev) for _ in range(4)]
+    Z = [torch.empty(M, 256, device=dev) for _ in range(4)]
+    y = [torch.empty(M, 128, device=dev) for _ in range(4)]
+    pa = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    lib.taco_highway4_fwd(x0, pa(W), pa(b), pa(Z), pa(y), M, stream())
+    x64 = x0.double().requires_grad_(True)
+    W64 = [w.double() for w in W]
+    cur, pre, outs = x64, [], []
+    for l in range(4):
+        z = cur @ W64[l] + b[l].double()
+        z.retain_grad()
+        pre.append(z)
+        # the ReLU on/off decision is taken from the kernel's own saved activation: a pre-activation within fp32 rounding of 0
+        # (about one unit in 1e7: expected at the largest M) may fall on either side, and the gradients below are compared on
+        # the kernel's linear piece; every such unit must be a float64 near-zero
+        on = Z[l][:, :128].double() > 0
+        flips = on != (z[:, :128].detach() > 0)
+        assert int(flips.sum()) <= 4 and (not bool(flips.any()) or float(z[:, :128].detach()[flips].abs().max()) < 1e-5)
+        H, T = z[:, :128] * on, torch.sigmoid(z[:, 128:])
+        cur = H * T + cur * (1 - T)
+        outs.append(cur)
+        assert rel(y[l].cpu().numpy(), cur.detach().cpu().numpy()) < 1e-5
+        assert rel(Z[l][:, :128].cpu().numpy(), H.detach().cpu().numpy()) < 1e-5
+        assert rel(Z[l][:, 128:].cpu().numpy(), T.detach().cpu().numpy()) < 1e-5
+    dy = torch.randn(M, 128, device=dev)
+    cur.backward(dy.double())
+    dZ = [torch.empty(M, 256, device=dev) for _ in range(4)]
+    dx = torch.empty(M, 128, device=dev)
+    xin = [x0] + y[:3]
+    lib.taco_highway4_bwd(dy, pa(Z), pa(xin), pa(W), pa(dZ), dx, M, stream())
+    torch.cuda.synchronize()
+    assert rel(dx.cpu().numpy(), x64.grad.cpu().numpy()) < 1e-5
+    for l in range(4):
+        assert rel(dZ[l].cpu().numpy(), pre[l].grad.cpu().numpy()) < 1e-5, l
+
+
 def test_empty_and_invalid_arguments_are_rejected():
     from tacotron_multispeaker_amd._lib import lib, stream
     x = torch.zeros(16, 8, device='cuda')
