@@ -131,7 +131,8 @@ struct Hw4B {
     int M;
 };
 #define HWB_LDZ (256 + 4)
-#define HWB_LDW (HW_BK + 4)
+#define HWB_BK 32                // K-chunk (Z columns) of the backward weight ring
+#define HWB_LDW (HWB_BK + 4)
 
 __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
     extern __shared__ __attribute__((aligned(16))) float hw_smem[];            // 70.7 KB
@@ -148,11 +149,16 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
         *reinterpret_cast<float4*>(&gs[r * HW_LDX + c4 * 4]) = a;
     }
     // weight chunk c of layer l: W_l[n][16 c .. +16] for all 128 rows n: 128 x 16 floats = 2 float4 per thread
-    float4 w0, w1;                      // thread covers W rows n = tid >> 2 and 64 + (tid >> 2), 4 of the 16 Z columns
-#define wload(l, c) do { const float* wp_ = HW_SEL(p.W, l) + (long)(tid >> 2) * 256 + (c) * HW_BK + (tid & 3) * 4; \
-        w0 = *reinterpret_cast<const float4*>(wp_); w1 = *reinterpret_cast<const float4*>(wp_ + 64 * 256); } while (0)
-#define wstore(dst) do { float* dp_ = (dst) + (tid >> 2) * HWB_LDW + (tid & 3) * 4; *reinterpret_cast<float4*>(dp_) = w0; \
-        *reinterpret_cast<float4*>(dp_ + 64 * HWB_LDW) = w1; } while (0)
+    // weight chunk c of layer l: W_l[n][32 c .. +32] for all 128 rows n = 1024 float4: thread covers rows (tid >> 3) + 32 v, v < 4
+    // (named registers and macros: a float4 array staged through helper functions or lambdas lands in scratch)
+    static_assert(HWB_BK == 32, "weight ring mapping");
+    float4 w0, w1, w2, w3;
+#define wload(l, c) do { const float* wp_ = HW_SEL(p.W, l) + (long)(tid >> 3) * 256 + (c) * HWB_BK + (tid & 7) * 4; \
+        w0 = *reinterpret_cast<const float4*>(wp_); w1 = *reinterpret_cast<const float4*>(wp_ + 32 * 256); \
+        w2 = *reinterpret_cast<const float4*>(wp_ + 64 * 256); w3 = *reinterpret_cast<const float4*>(wp_ + 96 * 256); } while (0)
+#define wstore(dst) do { float* dp_ = (dst) + (tid >> 3) * HWB_LDW + (tid & 7) * 4; *reinterpret_cast<float4*>(dp_) = w0; \
+        *reinterpret_cast<float4*>(dp_ + 32 * HWB_LDW) = w1; *reinterpret_cast<float4*>(dp_ + 64 * HWB_LDW) = w2; \
+        *reinterpret_cast<float4*>(dp_ + 96 * HWB_LDW) = w3; } while (0)
     __syncthreads();
     for (int l = 3; l >= 0; --l) {
         // ---- gate backward of the tile: thread = (row, 4 consecutive units); dZ to HBM + LDS, direct path into gs
@@ -188,19 +194,19 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         int stage = 0;
-        for (int c = 0; c < 256 / HW_BK; ++c) {
-            if (c + 1 < 256 / HW_BK) wload(l, c + 1);
+        for (int c = 0; c < 256 / HWB_BK; ++c) {
+            if (c + 1 < 256 / HWB_BK) wload(l, c + 1);
             const float* wsb = ws[stage];
 #pragma unroll
-            for (int kk = 0; kk < HW_BK / 8; ++kk) {
-                const float4 av = *reinterpret_cast<const float4*>(&zs[i * HWB_LDZ + c * HW_BK + kk * 8 + 4 * h]);
+            for (int kk = 0; kk < HWB_BK / 8; ++kk) {
+                const float4 av = *reinterpret_cast<const float4*>(&zs[i * HWB_LDZ + c * HWB_BK + kk * 8 + 4 * h]);
                 const float4 bv = *reinterpret_cast<const float4*>(&wsb[(32 * wave + i) * HWB_LDW + kk * 8 + 4 * h]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
             }
-            if (c + 1 < 256 / HW_BK) wstore(ws[stage ^ 1]);
+            if (c + 1 < 256 / HWB_BK) wstore(ws[stage ^ 1]);
             __syncthreads();
             stage ^= 1;
         }
@@ -249,7 +255,7 @@ extern "C" int taco_highway4_bwd(const float* dy, const float* const* HT4, const
         if (!HT4[l] || !xin4[l] || !W4[l] || !dZ4[l]) return TACO_EINVAL;
         p.HT[l] = HT4[l]; p.xin[l] = xin4[l]; p.W[l] = W4[l]; p.dZ[l] = dZ4[l];
     }
-    constexpr size_t smem = (32 * HW_LDX + 32 * HWB_LDZ + 2 * HW_D * HWB_LDW) * sizeof(float);
+    constexpr size_t smem = (32 * HW_LDX + 32 * HWB_LDZ + 2 * HW_D * HWB_LDW) * sizeof(float);      // 87 KB at HWB_BK = 32
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)highway4_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return TACO_EINVAL;

@@ -373,7 +373,7 @@ class Engine:
             self.dense_fwd(HW0, sc + '/highway_dense', hw, M, proj[1], 128)
         Zs = [self.buf('%s/hwZ%d' % (sc, i), M, 256) for i in range(1, 5)]
         ys = [self.buf('%s/hw%d' % (sc, i), M, 128) for i in range(1, 5)]
-        if self.fused_highway:
+        if self.fused_highway and M >= self.FUSED_HIGHWAY_MIN_ROWS:
             # the four layers in one launch: the tile's activations stay in LDS, [W_H | W_T] streams through an LDS ring
             pa = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
             self._timed('highway x4 fwd (highway4_fwd_k)', 4 * 2.0 * M * 128 * 256,
@@ -420,7 +420,7 @@ class Engine:
         other = self.buf(sc + '/dhw_b', M, 128)
         hw_ins = [(b[sc + '/hwd'] if proj[1] != 128 else b[sc + '/hw0'])] + [b['%s/hw%d' % (sc, i)] for i in range(1, 4)]
         dZs = [self.buf('%s/dZ%d' % (sc, i), M, 256) for i in range(1, 5)]      # one per layer: read later by the side-stream dW GEMM
-        if self.fused_highway:
+        if self.fused_highway and M >= self.FUSED_HIGHWAY_MIN_ROWS:
             pa = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
             self._timed('highway x4 bwd (highway4_bwd_k)', 4 * 2.0 * M * 128 * 256,
                         lambda: lib.taco_highway4_bwd(dhw, pa([b['%s/hwZ%d' % (sc, i)] for i in range(1, 5)]), pa(hw_ins),
@@ -593,6 +593,9 @@ class Engine:
     # The GRU(256) cluster kernels hold <= 128 batch rows (4 workgroups per 2 rows on 256 CUs); rows are independent, so larger
     # batches run block by block on contiguous [n0:n1] row slices of the [N,S,*] tensors.
     GRU256_ROWS = 128
+    # the fused highway kernels pay from ~2 row tiles per CU on (post-net: 20480 rows); the encoder's 4096 rows are 64 / 128 tiles,
+    # i.e. one tile's latency, and stay on the per-layer GEMM + gate launches (62 + 131 us fused vs 52 + 84 us)
+    FUSED_HIGHWAY_MIN_ROWS = int(os.environ.get('TACO_FUSED_HIGHWAY_MIN_ROWS', '8192'))
     ATTN_ROWS = 64
 
     GRU256_XCHG = 64 * 2048        # granule slots of one GRU(256) row block (>= 64 clusters x (6 x 256 + 4))
