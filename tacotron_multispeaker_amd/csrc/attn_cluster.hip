@@ -127,7 +127,9 @@ __device__ __forceinline__ void gather_vec(const u64* region, float* lds0, float
 // 32 freed VGPRs keep the kernel free of scratch spills (with all 112 weight floats in registers the loop-invariant granule
 // addresses are spilled and reloaded inside the poll loops).  The register variant remains for long inputs whose key / memory
 // tiles need the LDS (T_in > ~160).
-template <bool WLDS>
+// NT: register slots per lane of the per-wave softmax = ceil(T_in / 64), compiled for 2 (T_in <= 128: the C2 / C4 shapes) and 5
+// (T_in <= 320 covers everything the cluster path holds): with 8 slots unrolled, 6 of 8 iterations ran predicated-off at T_in = 128.
+template <bool WLDS, int NT>
 __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -389,20 +391,20 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             const int row = wv >> 2;
             const float* er = a_l + row * Ti;
             float* ar = an_l + row * Ti;
-            float ev[8];                                   // Ti <= 512 values per row live in registers
+            float ev[NT];                                  // Ti <= 64 NT values per row live in registers
             float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const int t = lane + 64 * i; ev[i] = t < Ti ? er[t] : -INFINITY; mx = fmaxf(mx, ev[i]); }
+            for (int i = 0; i < NT; ++i) { const int t = lane + 64 * i; ev[i] = t < Ti ? er[t] : -INFINITY; mx = fmaxf(mx, ev[i]); }
             mx = wave_max_fast(mx);
             float sm = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { ev[i] = __builtin_amdgcn_exp2f((ev[i] - mx) * 1.4426950408889634f); sm += ev[i]; }
+            for (int i = 0; i < NT; ++i) { ev[i] = __builtin_amdgcn_exp2f((ev[i] - mx) * 1.4426950408889634f); sm += ev[i]; }
             sm = wave_sum_fast(sm);
             const float inv = __builtin_amdgcn_rcpf(sm);
             const unsigned arow = (row ? so1 : so0) * (unsigned)Ti;
             const bool wr = (wv & 3) == 0 && (lane & 7) == w && ok[row];       // member w stores t = w, w + 8, ... to HBM
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NT; ++i) {
                 const int t = lane + 64 * i;
                 if (t < Ti) { const float av = ev[i] * inv; ar[t] = av; if (wr) p.align[arow + t] = av; }
             }
@@ -446,7 +448,7 @@ static size_t attn_cluster_smem(int Ti, bool wlds = false) {
 static size_t attn_cluster_bwd_smem(int Ti, bool wlds);
 extern "C" int taco_attn_cluster_supported(int N, int Ti) {
     return (CW * ((N + 1) / 2) <= 256 && attn_cluster_smem(Ti) <= 160 * 1024 && attn_cluster_bwd_smem(Ti, false) <= 160 * 1024 &&
-            Ti >= 1 && Ti <= 512) ? 1 : 0;
+            Ti >= 1 && Ti <= 320) ? 1 : 0;       // per-wave softmax: <= 5 register slots per lane
 }
 
 // which forward kernel a (N, Ti) launch runs: 0 = per-step kernels, 1 = attn_cluster_fwd_k<true> (Whg slice in LDS), 2 = <false>
@@ -460,9 +462,10 @@ extern "C" int taco_attn_cluster_fwd_variant(int N, int Ti) {
 int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_cluster_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)attn_cluster_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return TACO_EINVAL;
+        const void* ks[4] = {(const void*)attn_cluster_fwd_k<false, 2>, (const void*)attn_cluster_fwd_k<true, 2>,
+                             (const void*)attn_cluster_fwd_k<false, 5>, (const void*)attn_cluster_fwd_k<true, 5>};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TACO_EINVAL;
         attr_set = true;
     }
     // granule epochs count the steps of the whole pass, so only the pass's first chunk launch needs a zero-filled buffer
@@ -470,10 +473,13 @@ int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
         return TACO_EINVAL;
     AttnClu q = p;
     q.xcd_local = xcd_local_allowed();
-    if (taco_attn_cluster_fwd_variant(p.N, p.Ti) == 1)
-        hipLaunchKernelGGL(attn_cluster_fwd_k<true>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_smem(p.Ti, true), st, q);
-    else
-        hipLaunchKernelGGL(attn_cluster_fwd_k<false>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_smem(p.Ti, false), st, q);
+    const dim3 grid(CW * ((p.N + 1) / 2));
+    const bool wlds = taco_attn_cluster_fwd_variant(p.N, p.Ti) == 1, small = p.Ti <= 128;
+    const size_t smem = attn_cluster_smem(p.Ti, wlds);
+    if (wlds && small) hipLaunchKernelGGL((attn_cluster_fwd_k<true, 2>), grid, dim3(AT), smem, st, q);
+    else if (wlds) hipLaunchKernelGGL((attn_cluster_fwd_k<true, 5>), grid, dim3(AT), smem, st, q);
+    else if (small) hipLaunchKernelGGL((attn_cluster_fwd_k<false, 2>), grid, dim3(AT), smem, st, q);
+    else hipLaunchKernelGGL((attn_cluster_fwd_k<false, 5>), grid, dim3(AT), smem, st, q);
     TACO_RETURN_LAST();
 }
 
@@ -529,7 +535,7 @@ __device__ __forceinline__ void gather_off(const u64* region, float* lds0, float
 // 112 weight floats in VGPRs the compiler spills ~58 loop-invariant dwords to scratch and reloads ~50 of them EVERY step
 // (each an exposed ~300-cycle scratch load on the recurrence chain: 16.2 vs 12.2 us/step); 64 KiB of LDS removes that.
 // The register variant remains for long inputs whose key/memory tiles need the LDS (Ti > ~150).
-template <bool WLDS>
+template <bool WLDS, int NT>
 __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -696,10 +702,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             const float* dr_ = de_l + row * Ti;
             const float* ar = a_l + row * Ti;
             float* er = ep_l + row * Ti;
-            float dv[8], av[8];                            // Ti <= 512 values per row live in registers
+            float dv[NT], av[NT];                          // Ti <= 64 NT values per row live in registers
             float dot = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NT; ++i) {
                 const int t = lane + 64 * i;
                 dv[i] = 0.f; av[i] = 0.f;
                 if (t < Ti) {
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             dot = wave_sum_fast(dot);
             const bool wr = (wv & 3) == 0 && (lane & 7) == w && ok[row];       // member w stores t = w, w + 8, ... to HBM
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NT; ++i) {
                 const int t = lane + 64 * i;
                 if (t < Ti) { const float de = av[i] * (dv[i] - dot); er[t] = de; if (wr) p.de[so[row] * (unsigned)Ti + t] = de; }
             }
@@ -902,9 +908,10 @@ extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_cluster_bwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)attn_cluster_bwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return TACO_EINVAL;
+        const void* ks[4] = {(const void*)attn_cluster_bwd_k<false, 2>, (const void*)attn_cluster_bwd_k<true, 2>,
+                             (const void*)attn_cluster_bwd_k<false, 5>, (const void*)attn_cluster_bwd_k<true, 5>};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TACO_EINVAL;
         attr_set = true;
     }
     if (attn_cluster_bwd_smem(p.Ti, false) > 160 * 1024) return TACO_EINVAL;
@@ -912,10 +919,13 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
         return TACO_EINVAL;
     AttnCluB q = p;
     q.xcd_local = xcd_local_allowed();
-    if (taco_attn_cluster_bwd_variant(p.N, p.Ti) == 1)
-        hipLaunchKernelGGL(attn_cluster_bwd_k<true>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, true), st, q);
-    else
-        hipLaunchKernelGGL(attn_cluster_bwd_k<false>, dim3(CW * ((p.N + 1) / 2)), dim3(AT), attn_cluster_bwd_smem(p.Ti, false), st, q);
+    const dim3 grid(CW * ((p.N + 1) / 2));
+    const bool wlds = taco_attn_cluster_bwd_variant(p.N, p.Ti) == 1, small = p.Ti <= 128;
+    const size_t smem = attn_cluster_bwd_smem(p.Ti, wlds);
+    if (wlds && small) hipLaunchKernelGGL((attn_cluster_bwd_k<true, 2>), grid, dim3(AT), smem, st, q);
+    else if (wlds) hipLaunchKernelGGL((attn_cluster_bwd_k<true, 5>), grid, dim3(AT), smem, st, q);
+    else if (small) hipLaunchKernelGGL((attn_cluster_bwd_k<false, 2>), grid, dim3(AT), smem, st, q);
+    else hipLaunchKernelGGL((attn_cluster_bwd_k<false, 5>), grid, dim3(AT), smem, st, q);
     if (p.s0 == 0)       // all chunks done: reduce over the S steps
         hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3(p.Ti, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
                            dkeys, dmem, dvpart, p.S, p.Ti);
