@@ -139,7 +139,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
     else { w = blockIdx.x & 7; cl = blockIdx.x >> 3; }
     const int Ti = p.Ti, S = p.S;
     const int row0 = cl * 2;
-    const bool ok[2] = {row0 < p.N, row0 + 1 < p.N};
+    // an odd batch's last cluster runs row N-1 twice: both copies compute and store identical bits, so no store is guarded
     const long rw[2] = {(long)min(row0, p.N - 1), (long)min(row0 + 1, p.N - 1)};
 
     // ---- LDS carve-up
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 a0 = fmaxf(a0 + f0, 0.f); a1 = fmaxf(a1 + f1v, 0.f);
                 p1_l[PIDX(j)] = a0; p1_l[PLEN(256) + PIDX(j)] = a1;
                 put_g(xP1 + j, epoch, a0, local); put_g(xP1 + 256 + j, epoch, a1, local);
-                if (ok[0]) p.p1[so0 * 256 + j] = a0;
-                if (ok[1]) p.p1[so1 * 256 + j] = a1;
+                p.p1[so0 * 256 + j] = a0;
+                p.p1[so1 * 256 + j] = a1;
             }
             STAMP(1);
             gather_vec<32>(xP1, p1_l, p1_l + PLEN(256), w, epoch, tid, p.err);
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 a0 = fmaxf(a0 + b2v, 0.f); a1 = fmaxf(a1 + b2v, 0.f);
                 p2_l[PIDX(j)] = a0; p2_l[PLEN(128) + PIDX(j)] = a1;
                 put_g(xP2 + j, epoch, a0, local); put_g(xP2 + 128 + j, epoch, a1, local);
-                if (ok[0]) p.p2[so0 * 128 + j] = a0;
-                if (ok[1]) p.p2[so1 * 128 + j] = a1;
+                p.p2[so0 * 128 + j] = a0;
+                p.p2[so1 * 128 + j] = a1;
             }
             STAMP(3);
             gather_vec<16>(xP2, p2_l, p2_l + PLEN(128), w, epoch, tid, p.err);
@@ -279,12 +279,12 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                     const float q0 = g0 * h_l[PIDX(j)], q1 = g1 * h_l[PLEN(256) + PIDX(j)];
                     rh_l[PIDX(j)] = q0; rh_l[PLEN(256) + PIDX(j)] = q1;
                     put_g(xRH + j, epoch, q0, local); put_g(xRH + 256 + j, epoch, q1, local);
-                    if (ok[0]) { p.r[so0 * 256 + j] = g0; p.rh[so0 * 256 + j] = q0; }
-                    if (ok[1]) { p.r[so1 * 256 + j] = g1; p.rh[so1 * 256 + j] = q1; }
+                    p.r[so0 * 256 + j] = g0; p.rh[so0 * 256 + j] = q0;
+                    p.r[so1 * 256 + j] = g1; p.rh[so1 * 256 + j] = q1;
                 } else {
                     u_l[cC - 32] = g0; u_l[32 + cC - 32] = g1;
-                    if (ok[0]) p.u[so0 * 256 + j] = g0;
-                    if (ok[1]) p.u[so1 * 256 + j] = g1;
+                    p.u[so0 * 256 + j] = g0;
+                    p.u[so1 * 256 + j] = g1;
                 }
             }
             STAMP(5);
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 const float hn1 = u1 * h_l[PLEN(256) + PIDX(j)] + (1.f - u1) * c1;
                 h_l[PIDX(j)] = hn0; h_l[PLEN(256) + PIDX(j)] = hn1;
                 put_g(xH + j, epoch, hn0, local); put_g(xH + 256 + j, epoch, hn1, local);
-                if (ok[0]) { p.c[so0 * 256 + j] = c0; p.hc[so0 * 512 + j] = hn0; }
-                if (ok[1]) { p.c[so1 * 256 + j] = c1; p.hc[so1 * 512 + j] = hn1; }
+                p.c[so0 * 256 + j] = c0; p.hc[so0 * 512 + j] = hn0;
+                p.c[so1 * 256 + j] = c1; p.hc[so1 * 512 + j] = hn1;
             }
             STAMP(7);
             gather_vec<32>(xH, h_l, h_l + PLEN(256), w, epoch, tid, p.err);
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
             if (pA == 0) {
                 q_l[cA] = a0; q_l[32 + cA] = a1;
-                if (ok[0]) p.q[so0 * 256 + 32 * w + cA] = a0;
-                if (ok[1]) p.q[so1 * 256 + 32 * w + cA] = a1;
+                p.q[so0 * 256 + 32 * w + cA] = a0;
+                p.q[so1 * 256 + 32 * w + cA] = a1;
             }
         }
         lds_barrier();
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
             sm = wave_sum_fast(sm);
             const float inv = __builtin_amdgcn_rcpf(sm);
             const unsigned arow = (row ? so1 : so0) * (unsigned)Ti;
-            const bool wr = (wv & 3) == 0 && (lane & 7) == w && ok[row];       // member w stores t = w, w + 8, ... to HBM
+            const bool wr = (wv & 3) == 0 && (lane & 7) == w;                // member w stores t = w, w + 8, ... to HBM
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int t = lane + 64 * i;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_fwd_k(AttnClu p) {
                 const int j = 32 * w + d;
                 ctx_l[row * PLEN(256) + PIDX(j)] = cx;
                 put_g(xCTX + row * 256 + j, epoch, cx, local);
-                if (ok[row]) p.hc[(row ? so1 : so0) * 512u + 256u + j] = cx;
+                p.hc[(row ? so1 : so0) * 512u + 256u + j] = cx;
             }
         }
         STAMP(13);
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     else { w = blockIdx.x & 7; cl = blockIdx.x >> 3; }
     const int Ti = p.Ti, S = p.S;
     const int row0 = cl * 2;
-    const bool ok[2] = {row0 < p.N, row0 + 1 < p.N};
+    // an odd batch's last cluster runs row N-1 twice: both copies compute and store identical bits, so no store is guarded
     const long rw[2] = {(long)min(row0, p.N - 1), (long)min(row0 + 1, p.N - 1)};
 
     float* dq_l = smem;                            // [2][PLEN(256)]
@@ -658,8 +658,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         if (pA == 0) {
             const float d0 = dce[0] + dcc0, d1 = dce[1] + dcc1;
             dctx_l[cA] = d0; dctx_l[32 + cA] = d1;
-            if (ok[0]) p.dctx[so[0] * 256 + jA] = d0;
-            if (ok[1]) p.dctx[so[1] * 256 + jA] = d1;
+            p.dctx[so[0] * 256 + jA] = d0;
+            p.dctx[so[1] * 256 + jA] = d1;
         }
         lds_barrier();
         for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 }
             }
             dot = wave_sum_fast(dot);
-            const bool wr = (wv & 3) == 0 && (lane & 7) == w && ok[row];       // member w stores t = w, w + 8, ... to HBM
+            const bool wr = (wv & 3) == 0 && (lane & 7) == w;                // member w stores t = w, w + 8, ... to HBM
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int t = lane + 64 * i;
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 const int j = 32 * w + dl;
                 dq_l[row * PLEN(256) + PIDX(j)] = x;
                 put_gi(xDQ, (unsigned)(row * 256 + j), epoch, x, local);
-                if (ok[row]) p.dq[so[row] * 256 + j] = x;
+                p.dq[so[row] * 256 + j] = x;
             }
         }
         gather_vec<32>(xDQ, dq_l, dq_l + PLEN(256), w, epoch, tid, p.err);
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     const float dcp = dhT[b] * (1.f - u_[b]) * (1.f - c_[b] * c_[b]);
                     dxp_l[b * PLEN(768) + PIDX(512 + jA)] = dcp;
                     put_gi(xDCP, (unsigned)(b * 256 + jA), epoch, dcp, local);
-                    if (ok[b]) p.dxp[so[b] * 768 + 512 + jA] = dcp;
+                    p.dxp[so[b] * 768 + 512 + jA] = dcp;
                 }
             }
             gather_off<32>(xDCP, dxp_l, dxp_l + PLEN(768), 512, w, epoch, tid, p.err);
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     dxp_l[b * PLEN(768) + PIDX(256 + jA)] = dgu;
                     put_gi(xDGR, (unsigned)(b * 256 + jA), epoch, dgr, local);
                     put_gi(xDGU, (unsigned)(b * 256 + jA), epoch, dgu, local);
-                    if (ok[b]) { p.dxp[so[b] * 768 + jA] = dgr; p.dxp[so[b] * 768 + 256 + jA] = dgu; }
+                    p.dxp[so[b] * 768 + jA] = dgr; p.dxp[so[b] * 768 + 256 + jA] = dgu;
                 }
             }
             gather2<32>(xDGR, xDGU, dxp_l, dxp_l + PLEN(768), 0, 256, w, epoch, tid, p.err);
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 b0 = p2v[0] > 0.f ? b0 : 0.f; b1 = p2v[1] > 0.f ? b1 : 0.f;
                 dp2_l[PIDX(jB)] = b0; dp2_l[PLEN(128) + PIDX(jB)] = b1;
                 put_gi(xDP2, (unsigned)(jB), epoch, b0, local); put_gi(xDP2, (unsigned)(128 + jB), epoch, b1, local);
-                if (ok[0]) p.dp2[so[0] * 128 + jB] = b0;
-                if (ok[1]) p.dp2[so[1] * 128 + jB] = b1;
+                p.dp2[so[0] * 128 + jB] = b0;
+                p.dp2[so[1] * 128 + jB] = b1;
             }
             // the recurrent carry is first needed in X4 of the next step: computed while the dp2 granules travel
             float a0 = 0.f, a1 = 0.f;
@@ -830,8 +830,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 a0 = p1v[0] > 0.f ? a0 : 0.f; a1 = p1v[1] > 0.f ? a1 : 0.f;
                 dp1_l[PIDX(jA)] = a0; dp1_l[PLEN(256) + PIDX(jA)] = a1;
                 put_gi(xDP1, (unsigned)(jA), epoch, a0, local); put_gi(xDP1, (unsigned)(256 + jA), epoch, a1, local);
-                if (ok[0]) p.dp1[so[0] * 256 + jA] = a0;
-                if (ok[1]) p.dp1[so[1] * 256 + jA] = a1;
+                p.dp1[so[0] * 256 + jA] = a0;
+                p.dp1[so[1] * 256 + jA] = a1;
             }
             gather_vec<32>(xDP1, dp1_l, dp1_l + PLEN(256), w, epoch, tid, p.err);
         }
@@ -850,8 +850,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         // (the next iteration's first LDS writes -- a_l, q_l, dctx_l -- are not read by X8: no barrier needed here)
     }
     if (p.s0 > 0 && pA == 0) {         // hand the carries to the launch of the previous chunk
-        if (ok[0]) { p.dhcarry[(unsigned)rw[0] * 256u + jA] = dhc0; p.dctxcarry[(unsigned)rw[0] * 256u + jA] = dcc0; }
-        if (ok[1]) { p.dhcarry[(unsigned)rw[1] * 256u + jA] = dhc1; p.dctxcarry[(unsigned)rw[1] * 256u + jA] = dcc1; }
+        p.dhcarry[(unsigned)rw[0] * 256u + jA] = dhc0; p.dctxcarry[(unsigned)rw[0] * 256u + jA] = dcc0;
+        p.dhcarry[(unsigned)rw[1] * 256u + jA] = dhc1; p.dctxcarry[(unsigned)rw[1] * 256u + jA] = dcc1;
     }
 }
 
