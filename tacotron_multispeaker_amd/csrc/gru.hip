@@ -44,26 +44,34 @@ struct GruSeq {
     float* rh;            // [ndir,N,T,128] r*h_{prev}         (for dW_h cand   = rh^T . dxp[:, 256:384])
 };
 
-__global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
+// NTH threads per workgroup: 512 (2 waves per SIMD: K of a gate column split over 2 lanes, of a candidate column over 4; default)
+// or 256 (one wave per SIMD: a gate column's whole K in one lane; 192 weight VGPRs per lane).  Measured at C2: the 256-thread form
+// takes 1.0 us per step against 0.76 us -- the step is bound by the dependent chain of a phase (LDS read -> FMA chain -> reduce ->
+// gate -> LDS write -> barrier), which gets LONGER with fewer, fatter lanes, not by instruction issue.  Two accumulation chains per
+// lane (below) shorten it a little (-26 us per training step).
+template <int NTH>
+__global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
+    constexpr int KSG = NTH / 256, KSC = NTH / 128;       // lanes per gate / candidate column
+    constexpr int KG = H / KSG, KC = H / KSC;             // K terms per lane
     const int tid = threadIdx.x;
     const int row = blockIdx.x, dir = blockIdx.y;
     __shared__ __attribute__((aligned(16))) float h_l[LLEN(H)];
     __shared__ __attribute__((aligned(16))) float rh_l[LLEN(H)];
     __shared__ float u_l[H];
 
-    const int gcol = tid >> 1, kh = tid & 1;        // gates: 256 columns x 2 K-halves
-    const int ccol = tid >> 2, kq = tid & 3;        // candidate: 128 columns x 4 K-quarters
-    f2 wg[32], wc[16];
+    const int gcol = tid / KSG, kh = tid % KSG;     // gates: 256 columns x KSG K-parts
+    const int ccol = tid / KSC, kq = tid % KSC;     // candidate: 128 columns x KSC K-parts
+    f2 wg[KG / 2], wc[KC / 2];
     {
         const float* Wg = p.wg[dir];
         const float* Wc = p.wc[dir];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) wg[k] = (f2){Wg[(kh * 64 + 2 * k) * 256 + gcol], Wg[(kh * 64 + 2 * k + 1) * 256 + gcol]};
+        for (int k = 0; k < KG / 2; ++k) wg[k] = (f2){Wg[(kh * KG + 2 * k) * 256 + gcol], Wg[(kh * KG + 2 * k + 1) * 256 + gcol]};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wc[k] = (f2){Wc[(kq * 32 + 2 * k) * H + ccol], Wc[(kq * 32 + 2 * k + 1) * H + ccol]};
+        for (int k = 0; k < KC / 2; ++k) wc[k] = (f2){Wc[(kq * KC + 2 * k) * H + ccol], Wc[(kq * KC + 2 * k + 1) * H + ccol]};
     }
     const int len = p.lengths ? min(max(p.lengths[row], 0), p.T) : p.T;
-    for (int i = tid; i < LLEN(H); i += GT) { h_l[i] = 0.0f; rh_l[i] = 0.0f; }
+    for (int i = tid; i < LLEN(H); i += NTH) { h_l[i] = 0.0f; rh_l[i] = 0.0f; }
     __syncthreads();
 
     const int xoff = dir * 3 * H;
@@ -89,13 +97,15 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
         // ---- gates
         float a;
         {
-            const float* hp = h_l + LIDX(kh * 64);
-            f2 a2 = {0.0f, 0.0f};
+            f2 a2 = {0.0f, 0.0f}, a3 = {0.0f, 0.0f};          // two accumulation chains
 #pragma unroll
-            for (int k4 = 0; k4 < 16; ++k4) pk_dot4(*reinterpret_cast<const float4*>(hp + LIDX(k4 * 4)), wg + 2 * k4, a2);
-            a = a2.x + a2.y;
+            for (int k4 = 0; k4 < KG / 4; k4 += 2) {
+                pk_dot4(*reinterpret_cast<const float4*>(h_l + LIDX(kh * KG + k4 * 4)), wg + 2 * k4, a2);
+                pk_dot4(*reinterpret_cast<const float4*>(h_l + LIDX(kh * KG + k4 * 4 + 4)), wg + 2 * k4 + 2, a3);
+            }
+            a = (a2.x + a2.y) + (a3.x + a3.y);
         }
-        a = group_sum<2>(a);
+        a = group_sum<KSG>(a);
         if (kh == 0) {
             const float g = fast_sigmoid(a + ag);
             ruc[(long)t * 3 * H + gcol] = g;
@@ -106,13 +116,15 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
         // ---- candidate + state update
         float b;
         {
-            const float* qp = rh_l + LIDX(kq * 32);
-            f2 b2 = {0.0f, 0.0f};
+            f2 b2 = {0.0f, 0.0f}, b3 = {0.0f, 0.0f};
 #pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) pk_dot4(*reinterpret_cast<const float4*>(qp + k4 * 4), wc + 2 * k4, b2);
-            b = b2.x + b2.y;
+            for (int k4 = 0; k4 < KC / 4; k4 += 2) {
+                pk_dot4(*reinterpret_cast<const float4*>(rh_l + LIDX(kq * KC + k4 * 4)), wc + 2 * k4, b2);
+                pk_dot4(*reinterpret_cast<const float4*>(rh_l + LIDX(kq * KC + k4 * 4 + 4)), wc + 2 * k4 + 2, b3);
+            }
+            b = (b2.x + b2.y) + (b3.x + b3.y);
         }
-        b = group_sum<4>(b);
+        b = group_sum<KSC>(b);
         if (kq == 0) {
             const float c = fast_tanh(b + ac);
             const float hprev = h_l[LIDX(ccol)];
@@ -129,25 +141,28 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_fwd_k(GruSeq p) {
 
 // BPTT twin.  Processing order is the reverse of the forward order of that direction.  Hidden index k is owned by
 // lane 4k (the jq == 0 lane of its 4-lane group); transposed weight rows Wc[k][:], Wg[k][:] are split over the group.
-__global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
+template <int NTH>
+__global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
+    constexpr int JS = NTH / 128;                   // lanes per hidden index (4 or 2)
+    constexpr int JC = H / JS, JG = 2 * H / JS;     // reduction terms per lane: candidate / gate product
     const int tid = threadIdx.x;
     const int row = blockIdx.x, dir = blockIdx.y;
-    const int k = tid >> 2, jq = tid & 3;
+    const int k = tid / JS, jq = tid % JS;
     __shared__ __attribute__((aligned(16))) float dcp_l[LLEN(H)];
     __shared__ __attribute__((aligned(16))) float dg_l[LLEN(2 * H)];
 
-    f2 wcT[16], wgT[32];
+    f2 wcT[JC / 2], wgT[JG / 2];
     {
         const float* Wg = p.wg[dir];
         const float* Wc = p.wc[dir];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 a = *reinterpret_cast<const float4*>(Wc + k * H + jq * 32 + q * 4);
+        for (int q = 0; q < JC / 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(Wc + k * H + jq * JC + q * 4);
             wcT[q * 2] = (f2){a.x, a.y}; wcT[q * 2 + 1] = (f2){a.z, a.w};
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 g = *reinterpret_cast<const float4*>(Wg + k * 256 + jq * 64 + q * 4);
+        for (int q = 0; q < JG / 4; ++q) {
+            const float4 g = *reinterpret_cast<const float4*>(Wg + k * 256 + jq * JG + q * 4);
             wgT[q * 2] = (f2){g.x, g.y}; wgT[q * 2 + 1] = (f2){g.z, g.w};
         }
     }
@@ -192,13 +207,15 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
         // ---- drh[k] = sum_j dcp[j] * Wc[k][j]
         float drh;
         {
-            const float* a = dcp_l + LIDX(jq * 32);
-            f2 d2 = {0.0f, 0.0f};
+            f2 d2 = {0.0f, 0.0f}, d3 = {0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) pk_dot4(*reinterpret_cast<const float4*>(a + q * 4), wcT + 2 * q, d2);
-            drh = d2.x + d2.y;
+            for (int q = 0; q < JC / 4; q += 2) {
+                pk_dot4(*reinterpret_cast<const float4*>(dcp_l + LIDX(jq * JC + q * 4)), wcT + 2 * q, d2);
+                pk_dot4(*reinterpret_cast<const float4*>(dcp_l + LIDX(jq * JC + q * 4 + 4)), wcT + 2 * q + 2, d3);
+            }
+            drh = (d2.x + d2.y) + (d3.x + d3.y);
         }
-        drh = group_sum<4>(drh);
+        drh = group_sum<JS>(drh);
         if (owner) {
             dh_new += drh * r;
             const float dgr = drh * hprev * r * (1.0f - r);
@@ -214,16 +231,21 @@ __global__ __launch_bounds__(GT, 2) void gru128_seq_bwd_k(GruSeq p) {
         // ---- dh_{prev}[k] += sum_j dg[j] * Wg[k][j]   (j over 256, quarter of 64 per lane)
         float e;
         {
-            const float* a = dg_l + LIDX(jq * 64);
-            f2 e2 = {0.0f, 0.0f};
+            f2 e2 = {0.0f, 0.0f}, e3 = {0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < 16; ++q) pk_dot4(*reinterpret_cast<const float4*>(a + LIDX(q * 4)), wgT + 2 * q, e2);
-            e = e2.x + e2.y;
+            for (int q = 0; q < JG / 4; q += 2) {
+                pk_dot4(*reinterpret_cast<const float4*>(dg_l + LIDX(jq * JG + q * 4)), wgT + 2 * q, e2);
+                pk_dot4(*reinterpret_cast<const float4*>(dg_l + LIDX(jq * JG + q * 4 + 4)), wgT + 2 * q + 2, e3);
+            }
+            e = (e2.x + e2.y) + (e3.x + e3.y);
         }
-        e = group_sum<4>(e);
+        e = group_sum<JS>(e);
         dh = dh_new + e;
     }
 }
+
+// TACO_GRU128_THREADS = 256 | 512 (default 512; measured: 256 threads = one wave per SIMD is 27 % SLOWER per step, see gru128_seq_fwd_k)
+static int gru128_threads() { const char* e = getenv("TACO_GRU128_THREADS"); return (e && atoi(e) == 256) ? 256 : 512; }
 
 extern "C" int taco_gru128_seq_fwd(const float* xp, int ldxp, const float* wg_fw, const float* wc_fw, const float* wg_bw,
                                    const float* wc_bw, const int* lengths, float* out, int ldo, float* ruc, int N, int T,
@@ -233,7 +255,8 @@ extern "C" int taco_gru128_seq_fwd(const float* xp, int ldxp, const float* wg_fw
     GruSeq p{};
     p.xp = xp; p.ldxp = ldxp; p.wg[0] = wg_fw; p.wc[0] = wc_fw; p.wg[1] = wg_bw; p.wc[1] = wc_bw;
     p.lengths = lengths; p.out = out; p.ldo = ldo; p.ruc = ruc; p.N = N; p.T = T;
-    hipLaunchKernelGGL(gru128_seq_fwd_k, dim3(N, ndir), dim3(GT), 0, stream, p);
+    if (gru128_threads() == 256) hipLaunchKernelGGL(gru128_seq_fwd_k<256>, dim3(N, ndir), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gru128_seq_fwd_k<512>, dim3(N, ndir), dim3(512), 0, stream, p);
     TACO_RETURN_LAST();
 }
 
@@ -247,6 +270,7 @@ extern "C" int taco_gru128_seq_bwd(const float* dout, int lddo, const float* wg_
     p.ldxp = ldxp; p.wg[0] = wg_fw; p.wc[0] = wc_fw; p.wg[1] = wg_bw; p.wc[1] = wc_bw;
     p.lengths = lengths; p.out = const_cast<float*>(out); p.ldo = ldo; p.ruc = const_cast<float*>(ruc); p.N = N; p.T = T;
     p.dout = dout; p.lddo = lddo; p.dxp = dxp; p.hp = hp; p.rh = rh;
-    hipLaunchKernelGGL(gru128_seq_bwd_k, dim3(N, ndir), dim3(GT), 0, stream, p);
+    if (gru128_threads() == 256) hipLaunchKernelGGL(gru128_seq_bwd_k<256>, dim3(N, ndir), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gru128_seq_bwd_k<512>, dim3(N, ndir), dim3(512), 0, stream, p);
     TACO_RETURN_LAST();
 }
