@@ -282,6 +282,9 @@ def main():
         exposed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in eng.exposed_events[-a.steps:]]))
         eng.exposed_events = None
 
+    # the instrumented steps contain the gradient exchange: EVERY rank runs them (a collective issued by rank 0 alone would hang)
+    fams = kernel_families(eng, eager_step) if not a.no_families else None
+    barrier()
     if rank == 0:
         ms = dt / a.steps * 1e3
         frames = world * N * To
@@ -306,8 +309,7 @@ def main():
             out['allreduce_exposed_ms'] = exposed
         if err:
             out['error'] = 'a persistent cluster kernel reported a hand-off timeout: the timed steps are INVALID'
-        if not a.no_families:
-            fams = kernel_families(eng, eager_step)
+        if fams is not None:
             out['roofline'] = dict(fams[0], timing='HIP events around every launch of the family on its stream, 5 eager steps of the '
                                                    'same workload after the timed region')
             out['kernel_families'] = fams[1:]
