@@ -20,8 +20,10 @@
 #define HW_SEL(arr, l) ((l) == 0 ? (arr)[0] : (l) == 1 ? (arr)[1] : (l) == 2 ? (arr)[2] : (arr)[3])
 
 // ---------------------------------------------------------------------------------------------------------------------
-// forward: tile = 64 rows, 4 waves as 2 (row halves) x 2 (column halves); wave (wm, wn) computes rows [32 wm, +32) and the H
-// columns [64 wn, +64) together with the matching T columns [128 + 64 wn, +64): H and T of one unit meet in one lane.
+// forward: tile = 32 rows, 4 waves side by side: wave w computes all 32 rows of the H columns [32 w, +32) together with the
+// matching T columns [128 + 32 w, +32): H and T of one unit meet in one lane.  (A 64-row tile with 2 x 2 waves gave 320
+// workgroups at the post-net's 20480 rows: 64 CUs held two of them and set the kernel time; 640 workgroups of 50 KB LDS are one
+// round at three per CU.)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Hw4 {
     const float* x0;             // [M,128] input of layer 1
@@ -31,16 +33,17 @@ struct Hw4 {
     float* y[4];                 // [M,128] out: layer outputs
     int M;
 };
+#define HWF_ROWS 32
 
-__global__ __launch_bounds__(256, 2) void highway4_fwd_k(Hw4 p) {
-    extern __shared__ __attribute__((aligned(16))) float hw_smem[];            // 66.5 KB: over the 64 KB static limit
-    float* xs = hw_smem;                                   // [64][HW_LDX] activations of the tile (in place)
-    float (*ws)[HW_BK * 256] = reinterpret_cast<float (*)[HW_BK * 256]>(hw_smem + 64 * HW_LDX);   // weight ring: [2][k][256 columns]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+__global__ __launch_bounds__(256, 3) void highway4_fwd_k(Hw4 p) {
+    extern __shared__ __attribute__((aligned(16))) float hw_smem[];
+    float* xs = hw_smem;                                   // [32][HW_LDX] activations of the tile (in place)
+    float (*ws)[HW_BK * 256] = reinterpret_cast<float (*)[HW_BK * 256]>(hw_smem + HWF_ROWS * HW_LDX);   // weight ring: [2][k][256 columns]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const long m0 = (long)blockIdx.x * 64;
+    const long m0 = (long)blockIdx.x * HWF_ROWS;
     // ---- stage the input tile
-    for (int v = tid; v < 64 * 32; v += 256) {
+    for (int v = tid; v < HWF_ROWS * 32; v += 256) {
         const int r = v >> 5, c4 = v & 31;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m0 + r < p.M) a = *reinterpret_cast<const float4*>(p.x0 + (m0 + r) * HW_D + c4 * 4);
@@ -58,32 +61,27 @@ __global__ __launch_bounds__(256, 2) void highway4_fwd_k(Hw4 p) {
     wstore(ws[0]);
     __syncthreads();
     int stage = 0;
+    const int colH = 32 * wave + i, colT = 128 + 32 * wave + i;
     for (int l = 0; l < 4; ++l) {
-        f32x16 acc[4];                                    // H blocks 0,1 | T blocks 0,1 (32 columns each)
+        f32x16 accH, accT;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) { accH[r] = 0.0f; accT[r] = 0.0f; }
         for (int c = 0; c < HW_D / HW_BK; ++c) {
             const bool last = (l == 3 && c == HW_D / HW_BK - 1);
             if (!last) { if (c + 1 < HW_D / HW_BK) wload(l, c + 1); else wload(l + 1, 0); }
             const float* wsb = ws[stage];
 #pragma unroll
             for (int kk = 0; kk < HW_BK / 8; ++kk) {
-                const float4 av = *reinterpret_cast<const float4*>(&xs[(32 * wm + i) * HW_LDX + c * HW_BK + kk * 8 + 4 * h]);
+                const float4 av = *reinterpret_cast<const float4*>(&xs[i * HW_LDX + c * HW_BK + kk * 8 + 4 * h]);
                 const float a[4] = {av.x, av.y, av.z, av.w};
-                float b[4][4];
+                float bh[4], bt[4];
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const int col = (nb < 2 ? 64 * wn + 32 * nb : 128 + 64 * wn + 32 * (nb - 2)) + i;
+                for (int q = 0; q < 4; ++q) { bh[q] = wsb[(kk * 8 + 4 * h + q) * 256 + colH]; bt[q] = wsb[(kk * 8 + 4 * h + q) * 256 + colT]; }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) b[nb][q] = wsb[(kk * 8 + 4 * h + q) * 256 + col];
+                for (int q = 0; q < 4; ++q) {
+                    accH = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bh[q], accH, 0, 0, 0);
+                    accT = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bt[q], accT, 0, 0, 0);
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[nb][q], acc[nb], 0, 0, 0);
             }
             if (!last) wstore(ws[stage ^ 1]);
             __syncthreads();                              // chunk consumed by every wave; the next one is visible
@@ -93,23 +91,19 @@ __global__ __launch_bounds__(256, 2) void highway4_fwd_k(Hw4 p) {
         const float* bl = HW_SEL(p.b, l);
         float* Zl = HW_SEL(p.Z, l);
         float* yl = HW_SEL(p.y, l);
+        const float bhv = bl[colH], btv = bl[colT];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int col = 64 * wn + 32 * nb + i;
-            const float bh = bl[col], bt = bl[128 + col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float hv = fmaxf(acc[nb][r] + bh, 0.f);
-                const float tv = sigmoidf_(acc[2 + nb][r] + bt);
-                const float xv = xs[row * HW_LDX + col];
-                const float o = hv * tv + xv * (1.f - tv);
-                xs[row * HW_LDX + col] = o;
-                if (m0 + row < p.M) {
-                    Zl[(m0 + row) * 256 + col] = hv;
-                    Zl[(m0 + row) * 256 + 128 + col] = tv;
-                    yl[(m0 + row) * HW_D + col] = o;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float hv = fmaxf(accH[r] + bhv, 0.f);
+            const float tv = sigmoidf_(accT[r] + btv);
+            const float xv = xs[row * HW_LDX + colH];
+            const float o = hv * tv + xv * (1.f - tv);
+            xs[row * HW_LDX + colH] = o;
+            if (m0 + row < p.M) {
+                Zl[(m0 + row) * 256 + colH] = hv;
+                Zl[(m0 + row) * 256 + colT] = tv;
+                yl[(m0 + row) * HW_D + colH] = o;
             }
         }
         __syncthreads();                                  // the layer's output tile is complete before the next layer reads it
@@ -131,11 +125,12 @@ struct Hw4B {
     int M;
 };
 #define HWB_LDZ (256 + 4)
-#define HWB_BK 32                // K-chunk (Z columns) of the backward weight ring
+#define HWB_BK 16                // K-chunk (Z columns) of the backward weight ring: 70.6 KB of LDS = two workgroups per CU
+                                 // (32: 87 KB, ONE workgroup per CU and 2.5 rounds of the 640 post-net tiles)
 #define HWB_LDW (HWB_BK + 4)
 
 __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
-    extern __shared__ __attribute__((aligned(16))) float hw_smem[];            // 70.7 KB
+    extern __shared__ __attribute__((aligned(16))) float hw_smem[];            // 70.6 KB
     float* gs = hw_smem;                                   // [32][HW_LDX] dy of the current layer (in place -> dx)
     float* zs = gs + 32 * HW_LDX;                          // [32][HWB_LDZ] dZ tile, k-contiguous (k = Z column)
     float (*ws)[HW_D * HWB_LDW] = reinterpret_cast<float (*)[HW_D * HWB_LDW]>(zs + 32 * HWB_LDZ);   // weight ring: [2][input unit n][16 Z columns]
@@ -148,45 +143,52 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
         if (m0 + r < p.M) a = *reinterpret_cast<const float4*>(p.dy + (m0 + r) * HW_D + c4 * 4);
         *reinterpret_cast<float4*>(&gs[r * HW_LDX + c4 * 4]) = a;
     }
-    // weight chunk c of layer l: W_l[n][16 c .. +16] for all 128 rows n: 128 x 16 floats = 2 float4 per thread
-    // weight chunk c of layer l: W_l[n][32 c .. +32] for all 128 rows n = 1024 float4: thread covers rows (tid >> 3) + 32 v, v < 4
+    // weight chunk c of layer l: W_l[n][16 c .. +16] for all 128 rows n = 512 float4: thread covers rows (tid >> 2) + 64 v, v < 2
     // (named registers and macros: a float4 array staged through helper functions or lambdas lands in scratch)
-    static_assert(HWB_BK == 32, "weight ring mapping");
-    float4 w0, w1, w2, w3;
-#define wload(l, c) do { const float* wp_ = HW_SEL(p.W, l) + (long)(tid >> 3) * 256 + (c) * HWB_BK + (tid & 7) * 4; \
-        w0 = *reinterpret_cast<const float4*>(wp_); w1 = *reinterpret_cast<const float4*>(wp_ + 32 * 256); \
-        w2 = *reinterpret_cast<const float4*>(wp_ + 64 * 256); w3 = *reinterpret_cast<const float4*>(wp_ + 96 * 256); } while (0)
-#define wstore(dst) do { float* dp_ = (dst) + (tid >> 3) * HWB_LDW + (tid & 7) * 4; *reinterpret_cast<float4*>(dp_) = w0; \
-        *reinterpret_cast<float4*>(dp_ + 32 * HWB_LDW) = w1; *reinterpret_cast<float4*>(dp_ + 64 * HWB_LDW) = w2; \
-        *reinterpret_cast<float4*>(dp_ + 96 * HWB_LDW) = w3; } while (0)
+    static_assert(HWB_BK == 16, "weight ring mapping");
+    float4 w0, w1;
+#define wload(l, c) do { const float* wp_ = HW_SEL(p.W, l) + (long)(tid >> 2) * 256 + (c) * HWB_BK + (tid & 3) * 4; \
+        w0 = *reinterpret_cast<const float4*>(wp_); w1 = *reinterpret_cast<const float4*>(wp_ + 64 * 256); } while (0)
+#define wstore(dst) do { float* dp_ = (dst) + (tid >> 2) * HWB_LDW + (tid & 3) * 4; *reinterpret_cast<float4*>(dp_) = w0; \
+        *reinterpret_cast<float4*>(dp_ + 64 * HWB_LDW) = w1; } while (0)
+    // saved activations of a layer ([H|T] 32 KB + layer input 16 KB per tile) are fetched into registers ONE LAYER AHEAD, while the
+    // MFMA loop of the layer above runs: loaded at the point of use, every layer exposed an HBM round trip of 48 KB per workgroup
+    // (plain unrolled loops on constant indices: staged through lambdas the arrays land in scratch)
+    float4 ph[4], pt[4], px[4];
+#define pfetch(l) do { const float* H_ = HW_SEL(p.HT, l); const float* X_ = HW_SEL(p.xin, l); \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) { \
+            const long m_ = m0 + (tid >> 5) + 8 * v; const int c_ = (tid & 31) * 4; \
+            ph[v] = pt[v] = px[v] = make_float4(0.f, 0.f, 0.f, 0.f); \
+            if (m_ < p.M) { ph[v] = *reinterpret_cast<const float4*>(H_ + m_ * 256 + c_); \
+                            pt[v] = *reinterpret_cast<const float4*>(H_ + m_ * 256 + 128 + c_); \
+                            px[v] = *reinterpret_cast<const float4*>(X_ + m_ * HW_D + c_); } } } while (0)
+    pfetch(3);
     __syncthreads();
     for (int l = 3; l >= 0; --l) {
         // ---- gate backward of the tile: thread = (row, 4 consecutive units); dZ to HBM + LDS, direct path into gs
         wload(l, 0);
-        const float* HTl = HW_SEL(p.HT, l);
-        const float* xl = HW_SEL(p.xin, l);
         float* dZl = HW_SEL(p.dZ, l);
-        for (int v = tid; v < 32 * 32; v += 256) {
-            const int r = v >> 5, c = (v & 31) * 4;
-            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f), dt = dh, dd = dh;
-            if (m0 + r < p.M) {
-                const long m = m0 + r;
-                const float4 hv = *reinterpret_cast<const float4*>(HTl + m * 256 + c);
-                const float4 tv = *reinterpret_cast<const float4*>(HTl + m * 256 + 128 + c);
-                const float4 xv = *reinterpret_cast<const float4*>(xl + m * HW_D + c);
-                const float4 g = *reinterpret_cast<const float4*>(&gs[r * HW_LDX + c]);
-                dh.x = hv.x > 0.f ? g.x * tv.x : 0.f; dh.y = hv.y > 0.f ? g.y * tv.y : 0.f;
-                dh.z = hv.z > 0.f ? g.z * tv.z : 0.f; dh.w = hv.w > 0.f ? g.w * tv.w : 0.f;
-                dt.x = g.x * (hv.x - xv.x) * tv.x * (1.f - tv.x); dt.y = g.y * (hv.y - xv.y) * tv.y * (1.f - tv.y);
-                dt.z = g.z * (hv.z - xv.z) * tv.z * (1.f - tv.z); dt.w = g.w * (hv.w - xv.w) * tv.w * (1.f - tv.w);
-                dd.x = g.x * (1.f - tv.x); dd.y = g.y * (1.f - tv.y); dd.z = g.z * (1.f - tv.z); dd.w = g.w * (1.f - tv.w);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = (tid >> 5) + 8 * v, c = (tid & 31) * 4;
+            const long m = m0 + r;
+            const float4 hv = ph[v], tv = pt[v], xv = px[v];
+            const float4 g = *reinterpret_cast<const float4*>(&gs[r * HW_LDX + c]);
+            float4 dh, dt, dd;
+            dh.x = hv.x > 0.f ? g.x * tv.x : 0.f; dh.y = hv.y > 0.f ? g.y * tv.y : 0.f;
+            dh.z = hv.z > 0.f ? g.z * tv.z : 0.f; dh.w = hv.w > 0.f ? g.w * tv.w : 0.f;
+            dt.x = g.x * (hv.x - xv.x) * tv.x * (1.f - tv.x); dt.y = g.y * (hv.y - xv.y) * tv.y * (1.f - tv.y);
+            dt.z = g.z * (hv.z - xv.z) * tv.z * (1.f - tv.z); dt.w = g.w * (hv.w - xv.w) * tv.w * (1.f - tv.w);
+            dd.x = g.x * (1.f - tv.x); dd.y = g.y * (1.f - tv.y); dd.z = g.z * (1.f - tv.z); dd.w = g.w * (1.f - tv.w);
+            if (m < p.M) {
                 *reinterpret_cast<float4*>(dZl + m * 256 + c) = dh;
                 *reinterpret_cast<float4*>(dZl + m * 256 + 128 + c) = dt;
             }
-            *reinterpret_cast<float4*>(&zs[r * HWB_LDZ + c]) = dh;
+            *reinterpret_cast<float4*>(&zs[r * HWB_LDZ + c]) = dh;      // rows beyond M: hv = tv = 0 -> dh = dt = 0, dd = g = 0
             *reinterpret_cast<float4*>(&zs[r * HWB_LDZ + 128 + c]) = dt;
             *reinterpret_cast<float4*>(&gs[r * HW_LDX + c]) = dd;          // same thread read g above: in place
         }
+        if (l > 0) pfetch(l - 1);                              // in flight during this layer's MFMA loop
         wstore(ws[0]);
         __syncthreads();
         // ---- dx[row][n] += sum_k dZ[row][k] W[n][k], k over the 256 Z columns
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
     }
 #undef wload
 #undef wstore
+#undef pfetch
 }
 
 extern "C" int taco_highway4_fwd(const float* x0, const float* const* W4, const float* const* b4, float* const* Z4, float* const* y4,
@@ -236,13 +239,13 @@ extern "C" int taco_highway4_fwd(const float* x0, const float* const* W4, const 
         if (!W4[l] || !b4[l] || !Z4[l] || !y4[l]) return TACO_EINVAL;
         p.W[l] = W4[l]; p.b[l] = b4[l]; p.Z[l] = Z4[l]; p.y[l] = y4[l];
     }
-    constexpr size_t smem = (64 * HW_LDX + 2 * HW_BK * 256) * sizeof(float);
+    constexpr size_t smem = (HWF_ROWS * HW_LDX + 2 * HW_BK * 256) * sizeof(float);      // 49.7 KB
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)highway4_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return TACO_EINVAL;
         attr = true;
     }
-    hipLaunchKernelGGL(highway4_fwd_k, dim3(cdiv(M, 64)), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(highway4_fwd_k, dim3(cdiv(M, HWF_ROWS)), dim3(256), smem, stream, p);
     TACO_RETURN_LAST();
 }
 
@@ -255,7 +258,7 @@ extern "C" int taco_highway4_bwd(const float* dy, const float* const* HT4, const
         if (!HT4[l] || !xin4[l] || !W4[l] || !dZ4[l]) return TACO_EINVAL;
         p.HT[l] = HT4[l]; p.xin[l] = xin4[l]; p.W[l] = W4[l]; p.dZ[l] = dZ4[l];
     }
-    constexpr size_t smem = (32 * HW_LDX + 32 * HWB_LDZ + 2 * HW_D * HWB_LDW) * sizeof(float);      // 87 KB at HWB_BK = 32
+    constexpr size_t smem = (32 * HW_LDX + 32 * HWB_LDZ + 2 * HW_D * HWB_LDW) * sizeof(float);      // 70.6 KB
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)highway4_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return TACO_EINVAL;
