@@ -32,6 +32,10 @@ typedef struct ihipStream_t* hipStream_t;
  * act: 0 none, 1 relu, 2 sigmoid, 3 tanh.  Dense layer: kw = 1, T = M. */
 int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin, int Cout,
                        int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate, hipStream_t stream);
+/* the same over the FRAMES [t0, t1) of every length-T sequence of X / Y [N*T, .] (taps read the full sequences: the rows a tap
+ * reaches outside [t0, t1) must already be final): the post-net conv bank runs chunk by chunk behind the decoder pipeline */
+int taco_conv_rows_fwd(const float* X, const float* W, const float* bias, float* Y, int N, int T, int t0, int t1, int Cin,
+                       int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, hipStream_t stream);
 /* dX (+)= conv_transpose(dY, W)   (gradient of the above wrt X) */
 int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* dX, int M, int T, int Cin, int Cout, int kw,
                             int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream);
@@ -77,6 +81,11 @@ int taco_col_sum(const float* x, int ldx, float* out, int M, int C, hipStream_t 
 #define TACO_BN_DSTAT(C) (TACO_BN_REPL * 3 * (C))
 int taco_bn_stats_fwd(const float* x, int ldx, const float* gamma, const float* beta, double* dstat_zeroed, float* mean,
                       float* var, float* rstd, float* scale, float* shift, int M, int C, float eps, hipStream_t stream);
+/* in two parts, for a tensor produced in pieces: per-column sums over the frames [t0, t1) of every length-T sequence (any number of
+ * calls into the same zeroed dstat), then the finalisation over all M = N*T rows */
+int taco_bn_stats_rows(const float* x, int ldx, double* dstat, int N, int T, int t0, int t1, int C, hipStream_t stream);
+int taco_bn_finalize(const double* dstat, const float* gamma, const float* beta, float* mean, float* var, float* rstd,
+                     float* scale, float* shift, int M, int C, float eps, hipStream_t stream);
 int taco_bn_infer_params(const float* moving_mean, const float* moving_var, const float* gamma, const float* beta,
                          float* scale, float* shift, int C, float eps, hipStream_t stream);
 /* y = [max over (t, t+1)] (x*scale+shift) [+ res] */

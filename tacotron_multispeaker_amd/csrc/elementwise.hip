@@ -85,6 +85,7 @@ struct ColRed {
     const float* mean; const float* rstd; const float* scale; const float* shift;
     float* out0; double* dstat;
     int M, C, T, pool, rows_per_block;
+    int seq_len, seq_t0, seq_rows;      // MODE 1 over the frames [seq_t0, seq_t0 + seq_rows) of every length-seq_len sequence (blockIdx.z = sequence); 0 = all M rows
 };
 
 __device__ __forceinline__ float4 f4fma(float4 a, float4 s, float4 b) {
@@ -117,8 +118,9 @@ __global__ __launch_bounds__(256) void col_reduce_k(ColRed p) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + tx) * 4;
     const bool active = c < p.C;
-    const long r0 = (long)blockIdx.y * p.rows_per_block;
-    const long r1 = min((long)p.M, r0 + p.rows_per_block);
+    const long base = p.seq_rows ? (long)blockIdx.z * p.seq_len + p.seq_t0 : 0;
+    const long r0 = base + (long)blockIdx.y * p.rows_per_block;
+    const long r1 = min(base + (long)(p.seq_rows ? p.seq_rows : p.M), r0 + p.rows_per_block);
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     float4 sc = s0, sh = s0, mu = s0, rs = s0;
     if (active && MODE == 2) {
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void col_reduce_k(ColRed p) {
         } else {
             // TACO_BN_REPL replicas of the per-column sums: same-address double atomics from hundreds of workgroups
             // serialise in L2 (34 us for a 21 MB tensor); the consumers add the replicas up
-            double* ds = p.dstat + (long)(blockIdx.y % TACO_BN_REPL) * 3 * p.C;
+            double* ds = p.dstat + (long)((blockIdx.y + blockIdx.z) % TACO_BN_REPL) * 3 * p.C;
             atomicAdd(ds + c + 0, (double)a.x); atomicAdd(ds + c + 1, (double)a.y);
             atomicAdd(ds + c + 2, (double)a.z); atomicAdd(ds + c + 3, (double)a.w);
             atomicAdd(ds + p.C + c + 0, (double)b.x); atomicAdd(ds + p.C + c + 1, (double)b.y);
@@ -528,6 +530,26 @@ extern "C" int taco_bn_stats_fwd(const float* x, int ldx, const float* gamma, co
     dim3 g; col_reduce_grid(M, C, g, p.rows_per_block);
     hipLaunchKernelGGL(col_reduce_k<1>, g, dim3(256), 0, stream, p);
     hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, stream, dstat_zeroed, gamma, beta, mean, var, rstd, scale, shift, M, C, eps);
+    TACO_RETURN_LAST();
+}
+
+// the same in two parts, for a tensor that is produced in pieces: sums over the frames [t0, t1) of every length-T sequence of x [N*T, C]
+// (any number of calls, in any order, into the same zeroed dstat), then the finalisation over all M = N*T rows
+extern "C" int taco_bn_stats_rows(const float* x, int ldx, double* dstat, int N, int T, int t0, int t1, int C, hipStream_t stream) {
+    if (!x || !dstat || (C & 3) || (ldx & 3) || N <= 0 || t0 < 0 || t1 > T || t0 >= t1) return TACO_EINVAL;
+    ColRed p{}; p.x = x; p.ldx = ldx; p.dstat = dstat; p.M = N * T; p.C = C; p.T = T;
+    p.seq_len = T; p.seq_t0 = t0; p.seq_rows = t1 - t0;
+    int rpb = cdiv(t1 - t0, cdiv(768, cdiv(C, 256) * N));
+    if (rpb < 64) rpb = 64;
+    rpb = (rpb + 3) & ~3;
+    p.rows_per_block = rpb;
+    hipLaunchKernelGGL(col_reduce_k<1>, dim3(cdiv(C, 256), cdiv(t1 - t0, rpb), N), dim3(256), 0, stream, p);
+    TACO_RETURN_LAST();
+}
+extern "C" int taco_bn_finalize(const double* dstat, const float* gamma, const float* beta, float* mean, float* var, float* rstd,
+                                float* scale, float* shift, int M, int C, float eps, hipStream_t stream) {
+    if (!dstat || !gamma || !beta || !mean || !var || !rstd || !scale || !shift || M <= 0 || C <= 0) return TACO_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 256)), dim3(256), 0, stream, dstat, gamma, beta, mean, var, rstd, scale, shift, M, C, eps);
     TACO_RETURN_LAST();
 }
 

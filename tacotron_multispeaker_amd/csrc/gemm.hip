@@ -38,6 +38,11 @@ struct ConvGemm {
 __device__ __forceinline__ long rowmap(const ConvGemm& p, int m) {
     return p.rb_len ? (long)(m / p.rb_len) * p.rb_stride + p.rb_off + (m % p.rb_len) : (long)m;
 }
+// position of logical row m inside its length-T sequence (tap-shift mask).  Row-blocked conv (frames [rb_off, rb_off + rb_len) of
+// every sequence, taco_conv_rows_fwd): the position in the FULL sequence; row-blocked dense layers have no taps (mask always true).
+__device__ __forceinline__ int seqpos(const ConvGemm& p, int m) {
+    return (p.rb_len && p.kw_hi > 1) ? p.rb_off + m % p.rb_len : m % p.T;
+}
 
 // ---- MFMA inner product on one staged K-tile -------------------------------------------------------
 // A tile: k-contiguous [BM][BK+4] (AKC) or k-strided [BK][BM];  B tile likewise with BN.
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nn(ConvGemm p) {
     int tpos[TA::NV];
     long arow[TA::NV];
 #pragma unroll
-    for (int v = 0; v < TA::NV; ++v) { tpos[v] = (m0 + TA::row(tid, v)) % p.T; arow[v] = rowmap(p, m0 + TA::row(tid, v)); }
+    for (int v = 0; v < TA::NV; ++v) { tpos[v] = seqpos(p, m0 + TA::row(tid, v)); arow[v] = rowmap(p, m0 + TA::row(tid, v)); }
 
     f32x16 acc[BM / 64][BN / 64];
 #pragma unroll
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nn2(ConvGemm p) {
 #pragma unroll
     for (int v = 0; v < NVA; ++v) {
         const int r = (v * 4 + wave) * RPI + lane / CPR;
-        tpos[v] = (m0 + r) % p.T;
+        tpos[v] = seqpos(p, m0 + r);
         arow[v] = (unsigned)rowmap(p, m0 + r);
         arok[v] = m0 + r < p.M;
         acol[v] = ((lane % CPR) ^ ((r / (64 / BK)) & (CPR - 1))) * 4;    // k offset (floats) of the chunk this lane fetches
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt(ConvGemm p) {
     int tpos[TA::NV];
     long arow[TA::NV];
 #pragma unroll
-    for (int v = 0; v < TA::NV; ++v) { tpos[v] = (m0 + TA::row(tid, v)) % p.T; arow[v] = rowmap(p, m0 + TA::row(tid, v)); }
+    for (int v = 0; v < TA::NV; ++v) { tpos[v] = seqpos(p, m0 + TA::row(tid, v)); arow[v] = rowmap(p, m0 + TA::row(tid, v)); }
 
     f32x16 acc[BM / 64][BN / 64];
 #pragma unroll
@@ -1108,6 +1113,24 @@ extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* b
     else { p.bank = 0; p.cpb = 0; p.N = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
     if (int e = check_common(p)) return e;
     if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
+    launch_nn(p, stream);
+    TACO_RETURN_LAST();
+}
+
+// conv1d / conv bank over the FRAMES [t0, t1) of every length-T sequence (all taps read the full sequences: rows outside [t0, t1) must
+// already hold their final values where a tap reaches them).  Lets the post-net's bank run chunk by chunk behind the decoder pipeline.
+extern "C" int taco_conv_rows_fwd(const float* X, const float* W, const float* bias, float* Y, int N, int T, int t0, int t1, int Cin,
+                                  int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, hipStream_t stream) {
+    ConvGemm p{};
+    const int len = t1 - t0;
+    if (N <= 0 || T <= 0 || len <= 0 || t0 < 0 || t1 > T || kw < 1) return TACO_EINVAL;
+    p.A = X; p.B = W; p.C = Y; p.bias = bias;
+    p.M = N * len; p.K = Cin; p.T = T; p.lda = ldx; p.ldc = ldy; p.act = act; p.accumulate = 0; p.splitk = 1;
+    p.rb_len = len; p.rb_stride = T; p.rb_off = t0;
+    if (bank_K > 0) { p.bank = 1; p.cpb = 128; p.N = bank_K * 128; p.ldb = 128; p.kw_lo = 1; p.kw_hi = bank_K; }
+    else { p.bank = 0; p.cpb = 0; p.N = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
+    if (int e = check_common(p)) return e;
+    if (p.K & 3) return TACO_EINVAL;
     launch_nn(p, stream);
     TACO_RETURN_LAST();
 }

@@ -114,6 +114,7 @@ class Engine:
         self._deferred = []
         self.stream_b = torch.cuda.Stream(device=self.dev, priority=pr[0])      # decoder pipeline stages (GRU1 / GRU2 or attention)
         self.stream_c = torch.cuda.Stream(device=self.dev, priority=pr[0])
+        self.stream_d = torch.cuda.Stream(device=self.dev, priority=pr[0])      # post-net conv bank pieces behind the decoder pipeline
         self.main_stream = torch.cuda.Stream(device=self.dev, priority=pr[0]) if pr[0] != 0 else None
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
@@ -121,6 +122,7 @@ class Engine:
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.group_wgrad = os.environ.get('TACO_GROUP_WGRAD', '1') != '0'      # grouped weight / bias gradient launches
         self.fused_highway = os.environ.get('TACO_FUSED_HIGHWAY', '1') != '0'  # four highway layers in one launch per direction
+        self.post_pipe = os.environ.get('TACO_POST_PIPE', '1') != '0'          # post-net conv bank chunk by chunk behind the decoder
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
         self.world = 1                 # data-parallel replicas (set by train.py / bench.py after init_process_group)
         self.comm_stream = torch.cuda.Stream(device=self.dev)    # bucket all-reduces are ordered behind this stream
@@ -329,9 +331,15 @@ class Engine:
             self.gemm_dx(dy, self.P(scope + '/kernel'), dx, M, cin, cout, acc=acc)
 
     # ---- conv + BN ------------------------------------------------------------------------------------------------
-    def bn_fwd(self, scope, x, M, C, training):
+    def bn_fwd(self, scope, x, M, C, training, dstat=None):
+        """dstat: the per-column sums were already accumulated (taco_bn_stats_rows, tensor produced in pieces): finalise only."""
         sc, sh = self.buf(scope + '/bn_scale', C), self.buf(scope + '/bn_shift', C)
-        if training:
+        if training and dstat is not None:
+            lib.taco_bn_finalize(dstat, self.P(scope + '/gamma'), self.P(scope + '/beta'),
+                                 self.L.bnview(self.bnbatch, scope + '/moving_mean'),
+                                 self.L.bnview(self.bnbatch, scope + '/moving_variance'),
+                                 self.buf(scope + '/bn_rstd', C), sc, sh, M, C, BN_EPS, self.st)
+        elif training:
             lib.taco_bn_stats_fwd(x, x.stride(-2), self.P(scope + '/gamma'), self.P(scope + '/beta'), self.dslot(24 * C),
                                   self.L.bnview(self.bnbatch, scope + '/moving_mean'),
                                   self.L.bnview(self.bnbatch, scope + '/moving_variance'),
@@ -349,12 +357,14 @@ class Engine:
                         self.G(scope + '/bias'), dx, dx.stride(-2), M, C, T, pool, relu, self.st)
 
     # ---- CBHG (models/modules.py:35-74) ----------------------------------------------------------------------------
-    def cbhg_fwd(self, sc, x, N, T, cin, K, proj, lengths, training):
+    def cbhg_fwd(self, sc, x, N, T, cin, K, proj, lengths, training, bank_dstat=None):
+        """bank_dstat: the conv bank output (buffer sc/bank) and its batch-norm sums were produced piecewise by the caller."""
         M, C, st = N * T, K * 128, self.st
         B = self.buf(sc + '/bank', M, C)
-        self.gemm(x, self.P(sc + '/conv_bank/kernel'), self.P(sc + '/conv_bank/bias'), B, M, cin, C, T=T, kw=K, bank=K,
-                  ldw=128, act=ACT_RELU)
-        s, h = self.bn_fwd(sc + '/conv_bank', B, M, C, training)
+        if bank_dstat is None:
+            self.gemm(x, self.P(sc + '/conv_bank/kernel'), self.P(sc + '/conv_bank/bias'), B, M, cin, C, T=T, kw=K, bank=K,
+                      ldw=128, act=ACT_RELU)
+        s, h = self.bn_fwd(sc + '/conv_bank', B, M, C, training, dstat=bank_dstat)
         PL = self.buf(sc + '/pool', M, C)
         lib.taco_bn_apply_fwd(B, C, s, h, None, 0, PL, C, M, C, T, 1, st)
         C1 = self.buf(sc + '/c1', M, proj[0])
@@ -515,7 +525,16 @@ class Engine:
         cur = torch.cuda.current_stream()
         sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
         Wp, bp = self.P('concat_projection/kernel'), self.P('concat_projection/bias')
-        for (s0, s1) in chunks:
+        MEL = self.buf('mel_out', N, To, nm)             # == decoder outputs [N,S,nm*r] (tacotron.py:97)
+        # Post-net conv bank behind the decoder pipeline: as soon as GRU2 has finished a chunk, its output projection, the bank conv
+        # of the frames that chunk completes (a conv of width k reaches k // 2 frames ahead) and their batch-norm sums run on the
+        # GRU2 stream, on the CUs the attention recurrence leaves idle; after the last chunk only its share (~14 %) is left.
+        pipe_post = self.post_pipe and training and len(chunks) > 1
+        if pipe_post:
+            Kp, Cp = 8, 8 * 128
+            Bpost, dst_post, done = self.buf('post_cbhg/bank', Mp, Cp), self.dslot(24 * Cp), 0
+            Wo, bo = self.P('output_projection/kernel'), self.P('output_projection/bias')
+        for ci, (s0, s1) in enumerate(chunks):
             for nb, tab in self._attn_ptrs:
                 self._timed('attention recurrence fwd (attn_cluster_fwd_k)', self._attn_flops(nb, Ti, s1 - s0),
                             lambda: lib.taco_attn_rnn_fwd(tab, self._dims(nb, S, Ti, s0, s1), self.st))
@@ -534,13 +553,32 @@ class Engine:
                 t = gb[2]['t']
                 self.gru256_fwd(gb[2]['XP'], self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), gb[1]['D'], t, gb[2]['D'],
                                 gb[2]['x'], N, S, s0, s1)
+                if pipe_post:
+                    ev3 = torch.cuda.Event(); ev3.record(sc_)
+            if pipe_post:
+                # on a stream of its own: queued on the GRU2 stream the pieces would sit in front of GRU2's next chunk
+                sd = self.stream_d
+                sd.wait_event(ev3)
+                with torch.cuda.stream(sd):
+                    self.dense_rows(gb[2]['D'], Wo, bo, MEL.view(Ms, nm * r), N, S, s0, s1, 256, nm * r, 256, nm * r)
+                    f1 = To if ci == len(chunks) - 1 else r * s1 - Kp // 2
+                    if f1 > done:
+                        f0 = done
+                        self._timed('fwd GEMM (conv_gemm_nn2)', self._gemm_flops(N * (f1 - f0), nm, Cp, Kp, Kp),
+                                    lambda: lib.taco_conv_rows_fwd(MEL.view(Mp, nm), self.P('post_cbhg/conv_bank/kernel'),
+                                                                   self.P('post_cbhg/conv_bank/bias'), Bpost, N, To, f0, f1, nm, Cp, Kp, Kp,
+                                                                   nm, 128, Cp, ACT_RELU, self.st))
+                        lib.taco_bn_stats_rows(Bpost, Cp, dst_post, N, To, f0, f1, Cp, self.st)
+                        done = f1
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
-        prev = gb[2]['D']
-        MEL = self.buf('mel_out', N, To, nm)             # == decoder outputs [N,S,nm*r] (tacotron.py:97)
-        self.dense_fwd(prev, 'output_projection', MEL.view(Ms, nm * r), Ms, 256, nm * r)
+        if pipe_post:
+            cur.wait_stream(self.stream_d)
+        if not pipe_post:
+            self.dense_fwd(gb[2]['D'], 'output_projection', MEL.view(Ms, nm * r), Ms, 256, nm * r)
         self._mark('decoder fwd')
-        POST = self.cbhg_fwd('post_cbhg', MEL.view(Mp, nm), N, To, nm, 8, (256, nm), None, training)
+        POST = self.cbhg_fwd('post_cbhg', MEL.view(Mp, nm), N, To, nm, 8, (256, nm), None, training,
+                             bank_dstat=dst_post if pipe_post else None)
         LIN = self.buf('lin_out', N, To, self.nf)
         self.gemm(POST, self.P('linear/kernel'), self.P('linear/bias'), LIN, Mp, 256, self.nf, ldw=L.ld_lin, ldy=self.nf)
         self._mark('post-net fwd')
@@ -595,7 +633,7 @@ class Engine:
     GRU256_ROWS = 128
     # the fused highway kernels pay from ~2 row tiles per CU on (post-net: 20480 rows); the encoder's 4096 rows are 64 / 128 tiles,
     # i.e. one tile's latency, and stay on the per-layer GEMM + gate launches (62 + 131 us fused vs 52 + 84 us)
-    FUSED_HIGHWAY_MIN_ROWS = int(os.environ.get('TACO_FUSED_HIGHWAY_MIN_ROWS', '8192'))
+    FUSED_HIGHWAY_MIN_ROWS = int(os.environ.get('TACO_FUSED_HIGHWAY_MIN_ROWS', '4096'))
     ATTN_ROWS = 64
 
     GRU256_XCHG = 64 * 2048        # granule slots of one GRU(256) row block (>= 64 clusters x (6 x 256 + 4))
@@ -751,10 +789,16 @@ class Engine:
         self.loss_sums = self.dslot(32)                 # 2 losses x TACO_L1_REPL (8) replica pairs
         dMEL = self.buf('dmel_loss', Mp, self.nm) if with_grad else None
         dLIN = self.buf('dlin', Mp, self.L.ld_lin) if with_grad else None
-        lib.taco_l1_loss(self.mel_outputs, self.nm, self.mel_targets, self.nm, dMEL, self.nm, self.loss_sums, Mp, self.nm, 0,
-                         1.0 / (Mp * self.nm), 0.0, st)
+        # the (small) mel loss runs beside the linear loss on the second decoder stream
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(cur)
+        self.stream_b.wait_event(ev)
+        with torch.cuda.stream(self.stream_b):
+            lib.taco_l1_loss(self.mel_outputs, self.nm, self.mel_targets, self.nm, dMEL, self.nm, self.loss_sums, Mp, self.nm, 0,
+                             1.0 / (Mp * self.nm), 0.0, self.st)
         lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin,
                          self.loss_sums[16:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
+        cur.wait_stream(self.stream_b)
         self.reg_sum = None
         if self.has_regularity:
             # loss_regularity (tacotron.py:140-171): value + gradient wrt the alignments, consumed by the attention BPTT
