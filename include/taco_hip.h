@@ -39,6 +39,10 @@ int taco_conv_rows_fwd(const float* X, const float* W, const float* bias, float*
 /* dX (+)= conv_transpose(dY, W)   (gradient of the above wrt X) */
 int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* dX, int M, int T, int Cin, int Cout, int kw,
                             int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream);
+/* input gradient over the FRAMES [t0, t1) of every length-T sequence (reads dY rows of the whole sequences); a piece that is split
+ * over the taps adds partial sums atomically and therefore requires accumulate != 0 (dX pre-initialised by the caller) */
+int taco_conv_rows_bwd_data(const float* dY, const float* W, float* dX, int N, int T, int t0, int t1, int Cin, int Cout, int kw,
+                            int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream);
 /* dW += X^T (shifted per tap) . dY   (atomic accumulation into a zeroed / running gradient buffer) */
 int taco_conv_gemm_bwd_weight(const float* X, const float* dY, float* dW, int M, int T, int Cin, int Cout, int kw,
                               int bank_K, int ldx, int lddy, int ldw, hipStream_t stream);

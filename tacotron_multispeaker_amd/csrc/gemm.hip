@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void conv_gemm_nt2(ConvGemm p) {
 #pragma unroll
     for (int v = 0; v < NVA; ++v) {
         const int r = (v * 4 + wave) * RPI + lane / CPR;
-        tpos[v] = (m0 + r) % p.T;
+        tpos[v] = seqpos(p, m0 + r);
         arow[v] = (unsigned)rowmap(p, m0 + r);
         arok[v] = m0 + r < p.M;
         acol[v] = ((lane % CPR) ^ ((r / (64 / BK)) & (CPR - 1))) * 4;
@@ -1199,6 +1199,25 @@ extern "C" int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* d
     const int splitk = plan_nt(p);
     if (splitk > 1 && !accumulate)
         if (hipMemset2DAsync(dX, (size_t)lddx * sizeof(float), 0, (size_t)Cin * sizeof(float), M, stream) != hipSuccess) return TACO_EINVAL;
+    launch_nt(p, stream);
+    TACO_RETURN_LAST();
+}
+
+// input gradient over the FRAMES [t0, t1) of every length-T sequence (reads dY rows of the whole sequences).  accumulate: dX += ...;
+// a piece small enough to be split over the taps adds its partial sums atomically, so it REQUIRES accumulate (dX pre-initialised).
+// Lets the post-net bank's input gradient run chunk by chunk under the lead-in of the decoder backward.
+extern "C" int taco_conv_rows_bwd_data(const float* dY, const float* W, float* dX, int N, int T, int t0, int t1, int Cin, int Cout,
+                                       int kw, int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream) {
+    ConvGemm p{};
+    const int len = t1 - t0;
+    if (N <= 0 || T <= 0 || len <= 0 || t0 < 0 || t1 > T || kw < 1) return TACO_EINVAL;
+    p.A = dY; p.B = W; p.C = dX; p.bias = nullptr;
+    p.M = N * len; p.N = Cin; p.T = T; p.lda = lddy; p.ldc = lddx; p.act = ACT_NONE; p.accumulate = accumulate; p.splitk = 1;
+    p.rb_len = len; p.rb_stride = T; p.rb_off = t0;
+    if (bank_K > 0) { p.bank = 1; p.cpb = 128; p.K = 128; p.ldb = 128; p.kw_lo = 1; p.kw_hi = bank_K; }
+    else { p.bank = 0; p.K = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
+    if (int e = check_common(p)) return e;
+    if (plan_nt(p) > 1 && !accumulate) return TACO_EINVAL;
     launch_nt(p, stream);
     TACO_RETURN_LAST();
 }

@@ -404,7 +404,7 @@ class Engine:
                                                     self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC, N, T, 2, st))
         return OUT
 
-    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx, eager=False, after_proj2=None):
+    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx, eager=False, after_proj2=None, bank_dx_later=False):
         """dOUT [M,256] gradient wrt the CBHG output; writes the gradient wrt the CBHG input x into dx [M,cin].
         eager: release the deferred weight-gradient launches to the side stream after every block (encoder: nothing
         latency-bound follows that they could disturb, and held back they would run as a serial tail after the main stream)."""
@@ -472,6 +472,9 @@ class Engine:
         dB = self.buf(sc + '/dbank', M, C)
         self.bn_bwd(sc + '/conv_bank', b[sc + '/bank'], dPL, dB, M, C, T, 1, 1)
         self.gemm_dw(x, dB, self.G(sc + '/conv_bank/kernel'), M, cin, C, T=T, kw=K, bank=K, ldw=128)
+        if bank_dx_later:                  # the caller computes the bank's input gradient piecewise (and adds the residual dHW0)
+            flush()
+            return dB, dHW0
         self.gemm_dx(dB, self.P(sc + '/conv_bank/kernel'), dx, M, cin, C, T=T, kw=K, bank=K, ldw=128)
         flush()
         lib.taco_add(dx, dHW0, dx, M * cin, 0, st)        # residual connection (modules.py:56)
@@ -839,22 +842,48 @@ class Engine:
         self.colsum(dLIN, self.G('linear/bias'), Mp, L.ld_lin)
         dPOST = self.buf('dpost', Mp, 256)
         self.gemm_dx(dLIN, self.P('linear/kernel'), dPOST, Mp, 256, L.ld_lin, ldw=L.ld_lin)
-        dMELp = self.buf('dmel_post', Mp, nm)
-        self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, dMELp,
-                      eager=os.environ.get('TACO_POST_EAGER', '0') == '1')
+        chunks = self._chunks(N, S, Ti, self.pipe_chunks_bwd)[::-1]
+        cur = torch.cuda.current_stream()
+        dOUT = self.buf('dout', Ms, nm * r)
+        D2 = b['D2']
+        dD = self.buf('dD2', Ms, 256)
+        # Post-net bank input gradient under the lead-in of the decoder backward: the attention BPTT can only start once GRU2 and GRU1
+        # have done their first chunk (~0.23 ms in which 128 CUs idle), so the bank's dX (0.22 ms, the last GEMM of the post-net
+        # backward) is computed chunk by chunk, last chunk first, on a stream of its own: the decoder backward starts after the first
+        # piece.  dOUT starts as residual + mel-loss gradient and every piece ACCUMULATES into it.
+        pipe_post = self.post_pipe and len(chunks) > 1
+        if pipe_post:
+            dB, dHW0 = self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, None,
+                                     eager=os.environ.get('TACO_POST_EAGER', '0') == '1', bank_dx_later=True)
+            lib.taco_add(dHW0, b['dmel_loss'], dOUT, Mp * nm, 0, st)
+            evs = torch.cuda.Event(); evs.record(cur)
+            sd = self.stream_d
+            sd.wait_event(evs)
+            piece_done = []
+            with torch.cuda.stream(sd):
+                for (s0, s1) in chunks:
+                    f0, f1 = r * s0, r * s1
+                    self._timed('dX GEMM (conv_gemm_nt2)', self._gemm_flops(N * (f1 - f0), nm, 1024, 8, 8),
+                                lambda: lib.taco_conv_rows_bwd_data(dB, self.P('post_cbhg/conv_bank/kernel'), dOUT.view(Mp, nm), N, To, f0, f1,
+                                                                    nm, 1024, 8, 8, 1024, 128, nm, 1, self.st))
+                    e = torch.cuda.Event(); e.record(sd)
+                    piece_done.append(e)
+            # weight / bias gradient of the output projection: deferred; flushed after the last GRU2 chunk has waited for every piece
+            self.gemm_dw(D2, dOUT.view(Ms, nm * r), self.G('output_projection/kernel'), Ms, 256, nm * r)
+            self.colsum(dOUT.view(Ms, nm * r), self.G('output_projection/bias'), Ms, nm * r)
+        else:
+            dMELp = self.buf('dmel_post', Mp, nm)
+            self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, dMELp,
+                          eager=os.environ.get('TACO_POST_EAGER', '0') == '1')
         if nb >= 2:
             self._bucket_ready(0)                       # post-net + linear
         self._mark('post-net bwd')
-        dOUT = self.buf('dout', Ms, nm * r)
-        lib.taco_add(dMELp, b['dmel_loss'], dOUT, Mp * nm, 0, st)
-        # output projection
-        D2 = b['D2']
-        dD = self.buf('dD2', Ms, 256)
-        self.dense_bwd(D2, dOUT, 'output_projection', Ms, 256, nm * r, dx=dD)
+        if not pipe_post:
+            lib.taco_add(dMELp, b['dmel_loss'], dOUT, Mp * nm, 0, st)
+            # output projection
+            self.dense_bwd(D2, dOUT, 'output_projection', Ms, 256, nm * r, dx=dD)
         # Chunk-pipelined decoder backward (descending chunks): GRU2 BPTT on the current stream, GRU1 BPTT and the attention
         # BPTT on two more streams; the hoisted input-gradient projections of a chunk run between the stages.
-        chunks = self._chunks(N, S, Ti, self.pipe_chunks_bwd)[::-1]
-        cur = torch.cuda.current_stream()
         sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
         dHC = b['dHC']
         if self.no_cluster or not lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti):
@@ -866,6 +895,9 @@ class Engine:
         Wp = self.P('concat_projection/kernel')
         flush_at = min(len(chunks) - 1, int(os.environ.get('TACO_FLUSH_AT', '99')))
         for ci, (s0, s1) in enumerate(chunks):
+            if pipe_post:
+                cur.wait_event(piece_done[ci])
+                self.dense_rows_dx(dOUT.view(Ms, nm * r), self.P('output_projection/kernel'), dD, N, S, s0, s1, 256, nm * r, nm * r, 256, 0)
             R, U, C, RH, Hh = (b['g2_%s' % k] for k in ('r', 'u', 'c', 'rh', 'h'))
             self.gru256_bwd(dD, self.P('decoder_gru_2/whg'), self.P('decoder_gru_2/whc'), R, U, C, Hh, dxp[2], car[2], xg[2],
                             N, S, s0, s1)
