@@ -106,10 +106,11 @@ class Tacotron():
                     out.append(None)
                     continue
                 src = torch.as_tensor(np.ascontiguousarray(arr)).to(dt)
-                buf = slot.get(name)
-                if buf is None or buf.shape != src.shape:
-                    buf = torch.empty(src.shape, dtype=dt).pin_memory()
-                    slot[name] = buf
+                flat = slot.get(name)          # pinned capacity only grows (batch shapes change every step with the real feeder)
+                if flat is None or flat.numel() < src.numel():
+                    flat = torch.empty(max(src.numel(), 1), dtype=dt).pin_memory()
+                    slot[name] = flat
+                buf = flat[:src.numel()].view(src.shape)
                 buf.copy_(src)
                 out.append(buf.to(dev, non_blocking=True))
             ev = torch.cuda.Event()

@@ -103,6 +103,7 @@ class Engine:
         self.info = torch.zeros(4, **f)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._bufs = {}
+        self._flat = {}                # name -> flat storage (capacity only grows, see buf())
         self._dpos = 0
         # Stream priorities: the weight-gradient GEMMs of the side stream(s) are bulk work with slack; queued at the same priority
         # as the critical path their big grids hold the dispatcher while short critical kernels (highway / BN chains, the next
@@ -150,10 +151,23 @@ class Engine:
 
     # ---- workspace ------------------------------------------------------------------------------------------
     def buf(self, name, *shape, dtype=torch.float32):
+        """Named workspace tensor.  Capacity only grows: with the real feeder T_in / T_out change from batch to batch, and a
+        workspace keyed on the exact shape re-allocated and zero-filled ~150 tensors (1 GB at C2 sizes) on the host's critical path
+        every step.  A buffer whose shape changes is a new VIEW of the same storage and is NOT cleared: every kernel writes what it
+        (or its consumer) reads; the few tensors that must start at zero are zero-filled explicitly where they are used ('zeros' is
+        never written).  tests/test_gpu_parity.py::test_changing_batch_shapes_reuse_the_workspace holds this to fresh engines."""
         t = self._bufs.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.zeros(*shape, dtype=dtype, device=self.dev)
-            self._bufs[name] = t
+        if t is not None and t.dtype == dtype and tuple(t.shape) == tuple(shape):
+            return t
+        n = 1
+        for d in shape:
+            n *= int(d)
+        flat = self._flat.get(name)
+        if flat is None or flat.dtype != dtype or flat.numel() < n or name == 'zeros':
+            flat = torch.zeros(max(n, 1), dtype=dtype, device=self.dev)
+            self._flat[name] = flat
+        t = flat[:n].view(*shape)
+        self._bufs[name] = t
         return t
 
     def dslot(self, n):
@@ -634,8 +648,8 @@ class Engine:
     # The GRU(256) cluster kernels hold <= 128 batch rows (4 workgroups per 2 rows on 256 CUs); rows are independent, so larger
     # batches run block by block on contiguous [n0:n1] row slices of the [N,S,*] tensors.
     GRU256_ROWS = 128
-    # the fused highway kernels pay from ~2 row tiles per CU on (post-net: 20480 rows); the encoder's 4096 rows are 64 / 128 tiles,
-    # i.e. one tile's latency, and stay on the per-layer GEMM + gate launches (62 + 131 us fused vs 52 + 84 us)
+    # the fused highway kernels (32-row tiles) are used from the encoder's 4096 rows on (2 launches instead of 16, same time); smaller
+    # problems are one tile's latency and stay on the per-layer GEMM + gate launches
     FUSED_HIGHWAY_MIN_ROWS = int(os.environ.get('TACO_FUSED_HIGHWAY_MIN_ROWS', '4096'))
     ATTN_ROWS = 64
 

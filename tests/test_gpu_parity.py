@@ -770,6 +770,45 @@ def test_data_parallel_exchange_plumbing_single_rank_rccl():
         dist.destroy_process_group()
 
 
+def test_changing_batch_shapes_reuse_the_workspace():
+    """With the real feeder every batch has another (N, T_in, T_out).  The engine's workspace only grows and a buffer whose shape
+    changes is a new view of the SAME storage that is not cleared (Engine.buf), so every shape must give what a fresh engine gives:
+    big -> small (stale data behind and inside the views) -> other strides -> big again, pipelined (S >= 8) and unpipelined decoders,
+    free-running inference in between."""
+    from oracle import tacotron_np as onp
+    from tacotron_multispeaker_amd.engine import Engine
+    r = 5
+    P = onp.init_params(seed=5, r=r)
+    shapes = [(6, 40, 80, 11), (3, 17, 25, 12), (5, 33, 60, 13), (2, 40, 45, 14), (6, 40, 80, 11)]
+
+    def fwd_bwd(eng, b):
+        i, l, m, lin, ids = dev_batch(b, eng.dev)
+        eng.forward(i, l, m, ids)
+        eng.loss(lin)
+        eng.backward()
+        torch.cuda.synchronize()
+        eng.check_errors()
+        return dict(mel=eng.mel_outputs.cpu().numpy().copy(), lin=eng.linear_outputs.cpu().numpy().copy(),
+                    align=eng.alignments.cpu().numpy().copy(), loss=eng.loss_values()[0], grads=eng.export_named('grads'))
+
+    eng = Engine(r=r, named_params=P)
+    for k, (N, Ti, To, seed) in enumerate(shapes):
+        b = onp.synth_batch(N, Ti, To, r, seed=seed)
+        got = fwd_bwd(eng, b)
+        if k == 1:      # an inference pass re-views the same buffers with yet other shapes
+            i, l, _, _, _ = dev_batch(b, eng.dev)
+            eng.infer(i, l, steps=6)
+            torch.cuda.synchronize()
+            got = fwd_bwd(eng, b)
+        ref = fwd_bwd(Engine(r=r, named_params=P), b)
+        assert rel(got['mel'], ref['mel']) < 1e-6 and rel(got['lin'], ref['lin']) < 1e-6 and rel(got['align'], ref['align']) < 1e-6, (k, N, Ti, To)
+        assert abs(got['loss'] - ref['loss']) < 1e-6 * abs(ref['loss'])
+        gmax = max(float(np.abs(g).max()) for g in ref['grads'].values())
+        for n, g in ref['grads'].items():       # weight gradients accumulate with fp32 atomics: order noise only
+            d = float(np.abs(got['grads'][n].astype(np.float64) - g).max())
+            assert d < 2e-5 * float(np.abs(g).max()) + 1e-7 * gmax, (k, n)      # (bias-before-BN gradients are exactly 0 + noise)
+
+
 def test_model_api_synthesis_mode():
     """create_model('tacotron', hparams).initialize(inputs, input_lengths) -- the call synthesizer.py:26 makes."""
     import importlib
