@@ -326,6 +326,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()              # rank 0 is still timing / printing: nobody tears the communicator down under it
         dist.destroy_process_group()
 
 
