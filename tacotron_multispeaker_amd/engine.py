@@ -119,7 +119,7 @@ class Engine:
         self.main_stream = torch.cuda.Stream(device=self.dev, priority=pr[0]) if pr[0] != 0 else None
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
-        self.last_chunk_frac = float(os.environ.get('TACO_LAST_CHUNK', '0.5'))     # last chunk length / (S / chunks)
+        self.last_chunk_frac = float(os.environ.get('TACO_LAST_CHUNK', '0.7'))     # last chunk length / (S / chunks)
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.group_wgrad = os.environ.get('TACO_GROUP_WGRAD', '1') != '0'      # grouped weight / bias gradient launches
         self.fused_highway = os.environ.get('TACO_FUSED_HIGHWAY', '1') != '0'  # four highway layers in one launch per direction
