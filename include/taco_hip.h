@@ -35,7 +35,12 @@ int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float*
 /* the same over the FRAMES [t0, t1) of every length-T sequence of X / Y [N*T, .] (taps read the full sequences: the rows a tap
  * reaches outside [t0, t1) must already be final): the post-net conv bank runs chunk by chunk behind the decoder pipeline */
 int taco_conv_rows_fwd(const float* X, const float* W, const float* bias, float* Y, int N, int T, int t0, int t1, int Cin,
-                       int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, hipStream_t stream);
+                       int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, double* bn_stat, hipStream_t stream);
+/* conv + activation with the batch-norm sums of the output (tf.layers.batch_normalization after the conv, models/modules.py:95-101)
+ * accumulated from the accumulators in the GEMM epilogue instead of by a pass over Y; bn_stat: TACO_BN_DSTAT(Cout) zeroed doubles
+ * (taco_conv_rows_fwd: optional, may be NULL), finalised by taco_bn_finalize */
+int taco_conv_gemm_bn_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin, int Cout, int kw,
+                          int bank_K, int ldx, int ldw, int ldy, int act, double* bn_stat, hipStream_t stream);
 /* dX (+)= conv_transpose(dY, W)   (gradient of the above wrt X) */
 int taco_conv_gemm_bwd_data(const float* dY, const float* W, float* dX, int M, int T, int Cin, int Cout, int kw,
                             int bank_K, int lddy, int ldw, int lddx, int accumulate, hipStream_t stream);

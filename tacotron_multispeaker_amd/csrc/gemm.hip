@@ -31,6 +31,7 @@ struct ConvGemm {
     int accumulate;     // NN/NT: C += result
     int splitk;         // TN: reduction split
     int shift0;         // TN: extra row shift of X (dW of recurrent weights: X = H shifted by one step)
+    double* bn_stat;    // NN: optional batch-norm sums of the OUTPUT (after bias + activation): TACO_BN_REPL replicas of [sum | sum of squares | -] x N
     int rb_len, rb_stride, rb_off;   // NN/NT row blocking: logical row m -> physical row (m / rb_len) * rb_stride + rb_off + m % rb_len
                                      // (a chunk of steps [s0, s0+rb_len) of [N,S,*] tensors seen as one [N*rb_len, *] matrix); 0 = identity
 };
@@ -142,19 +143,32 @@ __device__ __forceinline__ void epilogue_store(const ConvGemm& p, f32x16 (&acc)[
 #pragma unroll
     for (int ni = 0; ni < BN / 64; ++ni) {
         const int col = n0 + wn * (BN / 2) + ni * 32 + i;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.0f;
+        const bool cok = col < p.N;
+        if (!cok && !p.bn_stat) continue;
+        const float bv = (cok && p.bias) ? p.bias[col] : 0.0f;
+        float s0 = 0.f, s1 = 0.f;           // batch-norm sums of this lane's 16 (32) rows of the column
 #pragma unroll
         for (int mi = 0; mi < BM / 64; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < p.M) {
+                if (cok && row < p.M) {
                     float* c = p.C + rowmap(p, row) * p.ldc + col;
                     float v = apply_act(acc[mi][ni][r] + bv, p.act);
                     if (p.accumulate) v += *c;
                     *c = v;
+                    s0 += v; s1 = fmaf(v, v, s1);
                 }
+            }
+        }
+        if (p.bn_stat) {
+            // tf.layers.batch_normalization statistics (modules.py:101) of the tensor this GEMM writes, straight from the accumulators:
+            // the two lane halves hold the other rows of the same column; one pair of double atomics per column and wave
+            s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+            if (h == 0 && cok) {
+                double* ds = p.bn_stat + (long)((m0 / BM) % TACO_BN_REPL) * 3 * p.N;
+                atomicAdd(ds + col, (double)s0);
+                atomicAdd(ds + p.N + col, (double)s1);
             }
         }
     }
@@ -979,7 +993,7 @@ __global__ __launch_bounds__(256) void conv_gemm_tn2(ConvGemm p) {
 // launch gaps and ramp-up/drain phases are a third of the stream's time and every launch is a new burst of workgroups
 // competing with the latency-bound recurrence kernels.  The problem table travels in the kernel arguments (no device table,
 // no host->device copy, HIP-graph capturable).
-#define TACO_WG_MAX 32
+#define TACO_WG_MAX 30
 struct WgradGroup {
     int count;
     int first[TACO_WG_MAX + 1];                 // first[i] = index of problem i's first workgroup; first[count] = grid size
@@ -1057,7 +1071,8 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
         if (p.K % BK_) hipLaunchKernelGGL((conv_gemm_nn2<BM_, BN_, BK_, ST_, true>), g2, dim3(256), 0, stream, p); \
         else hipLaunchKernelGGL((conv_gemm_nn2<BM_, BN_, BK_, ST_, false>), g2, dim3(256), 0, stream, p); } while (0)
 
-static void launch_nn(ConvGemm p, hipStream_t stream) {
+// returns the split count used (> 1: partial sums were added atomically, the epilogue never saw final values)
+static int launch_nn(ConvGemm p, hipStream_t stream) {
     static const int force_v1 = env_int("TACO_NN_V1", 0), force_cfg = env_int("TACO_NN2_TILE", -1);
     static const int no_split = env_int("TACO_NN_NOSPLIT", 0), split_min_m = env_int("TACO_NN_SPLIT_MINM", 1024);
     p.splitk = 1;
@@ -1070,7 +1085,7 @@ static void launch_nn(ConvGemm p, hipStream_t stream) {
             dim3 g(cdiv(p.M, 64), cdiv(p.N, 64));
             hipLaunchKernelGGL((conv_gemm_nn<64, 64, 32>), g, dim3(256), 0, stream, p);
         }
-        return;
+        return 1;
     }
     // few output tiles but a long reduction (encoder proj_1: 128 tiles x 192 steps): split the steps over blockIdx.z
     {
@@ -1100,28 +1115,48 @@ static void launch_nn(ConvGemm p, hipStream_t stream) {
         const long work = (long)p.M * p.N;
         hipLaunchKernelGGL(bias_act_k, dim3((int)((work + 1023) / 1024 > 2048 ? 2048 : (work + 1023) / 1024)), dim3(256), 0, stream, p);
     }
+    return p.splitk;
 }
 
+static int conv_gemm_fwd_impl(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin,
+                              int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate, double* bn_stat,
+                              hipStream_t stream);
 extern "C" int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin,
                                   int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate,
                                   hipStream_t stream) {
+    return conv_gemm_fwd_impl(X, W, bias, Y, M, T, Cin, Cout, kw, bank_K, ldx, ldw, ldy, act, accumulate, nullptr, stream);
+}
+// conv + activation with the batch-norm sums of the output accumulated in the epilogue (no extra pass over Y); bn_stat: TACO_BN_DSTAT(C)
+// zeroed doubles, finalised by taco_bn_finalize.  (A split-K launch cannot see final values: the sums are then taken by a pass over Y.)
+extern "C" int taco_conv_gemm_bn_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin,
+                                     int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, double* bn_stat,
+                                     hipStream_t stream) {
+    if (!bn_stat) return TACO_EINVAL;
+    return conv_gemm_fwd_impl(X, W, bias, Y, M, T, Cin, Cout, kw, bank_K, ldx, ldw, ldy, act, 0, bn_stat, stream);
+}
+static int conv_gemm_fwd_impl(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin,
+                              int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate, double* bn_stat,
+                              hipStream_t stream) {
     // bank_K > 0: fused conv bank (widths 1..bank_K, 128 channels each, outputs concatenated: Cout = bank_K*128)
     ConvGemm p{};
+    p.bn_stat = bn_stat;
     p.A = X; p.B = W; p.C = Y; p.bias = bias;
     p.M = M; p.K = Cin; p.T = T; p.lda = ldx; p.ldc = ldy; p.act = act; p.accumulate = accumulate; p.splitk = 1;
     if (bank_K > 0) { p.bank = 1; p.cpb = 128; p.N = bank_K * 128; p.ldb = 128; p.kw_lo = 1; p.kw_hi = bank_K; }
     else { p.bank = 0; p.cpb = 0; p.N = Cout; p.ldb = ldw; p.kw_lo = p.kw_hi = kw; }
     if (int e = check_common(p)) return e;
     if ((p.K & 3) || M % T != 0 || kw < 1) return TACO_EINVAL;
-    launch_nn(p, stream);
+    if (launch_nn(p, stream) > 1 && bn_stat)      // split-K: the sums come from a pass over Y
+        return taco_bn_stats_rows(Y, ldy, bn_stat, M / T, T, 0, T, p.N, stream);
     TACO_RETURN_LAST();
 }
 
 // conv1d / conv bank over the FRAMES [t0, t1) of every length-T sequence (all taps read the full sequences: rows outside [t0, t1) must
 // already hold their final values where a tap reaches them).  Lets the post-net's bank run chunk by chunk behind the decoder pipeline.
 extern "C" int taco_conv_rows_fwd(const float* X, const float* W, const float* bias, float* Y, int N, int T, int t0, int t1, int Cin,
-                                  int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, hipStream_t stream) {
+                                  int Cout, int kw, int bank_K, int ldx, int ldw, int ldy, int act, double* bn_stat, hipStream_t stream) {
     ConvGemm p{};
+    p.bn_stat = bn_stat;                 // optional: batch-norm sums of the rows written (no split-K on this path)
     const int len = t1 - t0;
     if (N <= 0 || T <= 0 || len <= 0 || t0 < 0 || t1 > T || kw < 1) return TACO_EINVAL;
     p.A = X; p.B = W; p.C = Y; p.bias = bias;

@@ -223,6 +223,14 @@ class Engine:
                     lambda: lib.taco_conv_gemm_fwd(X, W, bias, Y, M, T or M, Cin, Cout, kw, bank,
                                                    ldx or X.stride(-2), ldw or Cout, ldy or Y.stride(-2), act, acc, self.st))
 
+    def conv_bn(self, X, W, bias, Y, M, Cin, Cout, T, kw=1, bank=0, ldw=None, act=0):
+        """conv (+ activation) whose output is batch-normalised next: the BN sums come out of the GEMM epilogue.  Returns the sums."""
+        dst = self.dslot(24 * Cout)
+        self._timed('fwd GEMM (conv_gemm_nn2)', self._gemm_flops(M, Cin, Cout, kw, bank),
+                    lambda: lib.taco_conv_gemm_bn_fwd(X, W, bias, Y, M, T, Cin, Cout, kw, bank, X.stride(-2), ldw or Cout, Y.stride(-2),
+                                                      act, dst, self.st))
+        return dst
+
     def gemm_dx(self, dY, W, dX, M, Cin, Cout, T=None, kw=1, bank=0, lddy=None, ldw=None, lddx=None, acc=0):
         self._timed('dX GEMM (conv_gemm_nt2)', self._gemm_flops(M, Cin, Cout, kw, bank),
                     lambda: lib.taco_conv_gemm_bwd_data(dY, W, dX, M, T or M, Cin, Cout, kw, bank,
@@ -375,20 +383,32 @@ class Engine:
         """bank_dstat: the conv bank output (buffer sc/bank) and its batch-norm sums were produced piecewise by the caller."""
         M, C, st = N * T, K * 128, self.st
         B = self.buf(sc + '/bank', M, C)
-        if bank_dstat is None:
+        # training: the batch-norm sums of every conv output are taken in that conv's GEMM epilogue (conv_bn), not by a pass over it
+        if bank_dstat is None and training:
+            bank_dstat = self.conv_bn(x, self.P(sc + '/conv_bank/kernel'), self.P(sc + '/conv_bank/bias'), B, M, cin, C, T, kw=K, bank=K,
+                                      ldw=128, act=ACT_RELU)
+        elif bank_dstat is None:
             self.gemm(x, self.P(sc + '/conv_bank/kernel'), self.P(sc + '/conv_bank/bias'), B, M, cin, C, T=T, kw=K, bank=K,
                       ldw=128, act=ACT_RELU)
         s, h = self.bn_fwd(sc + '/conv_bank', B, M, C, training, dstat=bank_dstat)
         PL = self.buf(sc + '/pool', M, C)
         lib.taco_bn_apply_fwd(B, C, s, h, None, 0, PL, C, M, C, T, 1, st)
         C1 = self.buf(sc + '/c1', M, proj[0])
-        self.gemm(PL, self.P(sc + '/proj_1/kernel'), self.P(sc + '/proj_1/bias'), C1, M, C, proj[0], T=T, kw=3, act=ACT_RELU)
-        s, h = self.bn_fwd(sc + '/proj_1', C1, M, proj[0], training)
+        d1 = None
+        if training:
+            d1 = self.conv_bn(PL, self.P(sc + '/proj_1/kernel'), self.P(sc + '/proj_1/bias'), C1, M, C, proj[0], T, kw=3, act=ACT_RELU)
+        else:
+            self.gemm(PL, self.P(sc + '/proj_1/kernel'), self.P(sc + '/proj_1/bias'), C1, M, C, proj[0], T=T, kw=3, act=ACT_RELU)
+        s, h = self.bn_fwd(sc + '/proj_1', C1, M, proj[0], training, dstat=d1)
         Y1 = self.buf(sc + '/y1', M, proj[0])
         lib.taco_bn_apply_fwd(C1, proj[0], s, h, None, 0, Y1, proj[0], M, proj[0], T, 0, st)
         C2 = self.buf(sc + '/c2', M, proj[1])
-        self.gemm(Y1, self.P(sc + '/proj_2/kernel'), self.P(sc + '/proj_2/bias'), C2, M, proj[0], proj[1], T=T, kw=3)
-        s, h = self.bn_fwd(sc + '/proj_2', C2, M, proj[1], training)
+        d2 = None
+        if training:
+            d2 = self.conv_bn(Y1, self.P(sc + '/proj_2/kernel'), self.P(sc + '/proj_2/bias'), C2, M, proj[0], proj[1], T, kw=3)
+        else:
+            self.gemm(Y1, self.P(sc + '/proj_2/kernel'), self.P(sc + '/proj_2/bias'), C2, M, proj[0], proj[1], T=T, kw=3)
+        s, h = self.bn_fwd(sc + '/proj_2', C2, M, proj[1], training, dstat=d2)
         HW0 = self.buf(sc + '/hw0', M, proj[1])
         lib.taco_bn_apply_fwd(C2, proj[1], s, h, x, cin, HW0, proj[1], M, proj[1], T, 0, st)   # + residual
         hw = HW0
@@ -584,8 +604,7 @@ class Engine:
                         self._timed('fwd GEMM (conv_gemm_nn2)', self._gemm_flops(N * (f1 - f0), nm, Cp, Kp, Kp),
                                     lambda: lib.taco_conv_rows_fwd(MEL.view(Mp, nm), self.P('post_cbhg/conv_bank/kernel'),
                                                                    self.P('post_cbhg/conv_bank/bias'), Bpost, N, To, f0, f1, nm, Cp, Kp, Kp,
-                                                                   nm, 128, Cp, ACT_RELU, self.st))
-                        lib.taco_bn_stats_rows(Bpost, Cp, dst_post, N, To, f0, f1, Cp, self.st)
+                                                                   nm, 128, Cp, ACT_RELU, dst_post, self.st))
                         done = f1
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
