@@ -12,7 +12,8 @@ slots = eng._attn_slots(N, Ti)
 from tacotron_multispeaker_amd._lib import lib
 fw = lib.load().taco_attn_cluster_xchg_slots(N, Ti)
 st = eng._bufs['xchg_attn'][fw - 16:fw].cpu().numpy().astype(np.float64)
-S = To // r
+ch = eng._chunks(N, To // r, Ti)[-1]
+S = ch[1] - ch[0]                  # the stamps of the LAST launch (last chunk) survive
 names = ['loop/top', 'A p1 dot+publish', 'A gather+barrier', 'B p2 dot+publish', 'B gather+bar', 'C gates dot+publish', 'C cand-x dot+gather+bar',
          'D cand dot+publish', 'D gather+bar', 'E query+bar', 'F scores+publish+gh dot+gather+bar', '-', '-', 'GH softmax+ctx+publish', 'GH gather+bar', '-']
 tot = st.sum()

@@ -630,8 +630,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         if (pB == 0) { pf_p2[0] = p.p2[sl[0] * 128u + jB]; pf_p2[1] = p.p2[sl[1] * 128u + jB]; }
     }
     __syncthreads();
+    STAMP_DECL
 
     for (int s = p.s1 - 1; s >= p.s0; --s) {
+        STAMP(0);
         // Re-derive the lane indices from an opaque copy of the thread id every step: otherwise every LDS / granule address
         // built from them is hoisted out of the loop, and with 256 VGPRs full of weights the hoisted copies live in scratch
         // (reloaded on the recurrence chain each step).
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             p.dctx[so[1] * 256 + jA] = d1;
         }
         lds_barrier();
+        STAMP(1);
         for (int i = tid >> 1; i < 2 * Ti; i += AT / 2) {
             const int half = tid & 1, row = i >= Ti;
             const float* mp = M_l + i * 32 + half * 16;
@@ -690,7 +693,9 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             const float tot2 = dpp_add<0xB1>(sum);
             if (half == 0) de_l[i] = tot2;                        // da[row][t]
         }
+        STAMP(2);
         lds_barrier();
+        STAMP(3);
         // ================= X2+X3: softmax backward and dq slice, one pass per wave, no barrier in between =================
         // Wave v works on row v >> 2 and score dims 8 (v & 3) .. +8.  Every wave of a row recomputes de = a * (da - sum a*da)
         // for the whole row (the four waves write the same bits to ep_l and read back only their own writes), then
@@ -739,8 +744,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 p.dq[so[row] * 256 + j] = x;
             }
         }
+        STAMP(4);
         gather_vec<32>(xDQ, dq_l, dq_l + PLEN(256), w, epoch, tid, p.err);
         lds_barrier();
+        STAMP(5);
         // ================= X4: dhT = dh_ext + carry + dq . Wq^T ; candidate pre-activation gradient =================
         float dhT[2] = {0, 0}, du[2] = {0, 0}, dhd[2] = {0, 0};
         {
@@ -759,9 +766,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     p.dxp[so[b] * 768 + 512 + jA] = dcp;
                 }
             }
+            STAMP(6);
             gather_off<32>(xDCP, dxp_l, dxp_l + PLEN(768), 512, w, epoch, tid, p.err);
         }
         lds_barrier();
+        STAMP(7);
         // ================= X5: drh = dcp . Whc^T ; gate pre-activation gradients =================
         float dhp[2] = {0, 0};
         {
@@ -782,9 +791,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                     p.dxp[so[b] * 768 + jA] = dgr; p.dxp[so[b] * 768 + 256 + jA] = dgu;
                 }
             }
+            STAMP(8);
             gather2<32>(xDGR, xDGU, dxp_l, dxp_l + PLEN(768), 0, 256, w, epoch, tid, p.err);
         }
         lds_barrier();
+        STAMP(9);
         // ---- issue the loads for step s-1 (consumed at the top of the next iteration)
         if (s > p.s0) {
             const unsigned sn[2] = {so[0] - 1u, so[1] - 1u};
@@ -817,9 +828,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             dot2<32>(dxp_l, dxp_l + PLEN(768), pA * 32, wg, a0, a1);
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
             if (pA == 0) { dhc0 = dhp[0] + a0; dhc1 = dhp[1] + a1; }
+            STAMP(10);
             gather_vec<16>(xDP2, dp2_l, dp2_l + PLEN(128), w, epoch, tid, p.err);
         }
         lds_barrier();
+        STAMP(11);
         // ================= X7: dp1pre = (dp2pre . W2^T) * (p1 > 0) =================
         {
             float a0 = 0.f, a1 = 0.f;
@@ -833,9 +846,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
                 p.dp1[so[0] * 256 + jA] = a0;
                 p.dp1[so[1] * 256 + jA] = a1;
             }
+            STAMP(12);
             gather_vec<32>(xDP1, dp1_l, dp1_l + PLEN(256), w, epoch, tid, p.err);
         }
         lds_barrier();
+        STAMP(13);
         if (s > p.s0) {
             if (pA == 0) { pf_p1[0] = p.p1[(so[0] - 1u) * 256u + jA]; pf_p1[1] = p.p1[(so[1] - 1u) * 256u + jA]; }
             if (pB == 0) { pf_p2[0] = p.p2[(so[0] - 1u) * 128u + jB]; pf_p2[1] = p.p2[(so[1] - 1u) * 128u + jB]; }
@@ -847,8 +862,10 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             a0 = lane_reduce<16>(a0); a1 = lane_reduce<16>(a1);
             if (pA == 0) { dcc0 = a0; dcc1 = a1; }
         }
+        STAMP(14);
         // (the next iteration's first LDS writes -- a_l, q_l, dctx_l -- are not read by X8: no barrier needed here)
     }
+    STAMP_OUT(p.xchg + (long)nclus * (per_clu + CW));
     if (p.s0 > 0 && pA == 0) {         // hand the carries to the launch of the previous chunk
         p.dhcarry[(unsigned)rw[0] * 256u + jA] = dhc0; p.dctxcarry[(unsigned)rw[0] * 256u + jA] = dcc0;
         p.dhcarry[(unsigned)rw[1] * 256u + jA] = dhc1; p.dctxcarry[(unsigned)rw[1] * 256u + jA] = dcc1;
@@ -902,7 +919,7 @@ extern "C" int taco_attn_cluster_bwd_variant(int N, int Ti) {
 }
 
 extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
-    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128 + CW);       // + CW placement granules per cluster
+    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128 + CW) + 16;  // + CW placement granules per cluster; + 16 diagnostic stamp slots
 }
 
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
@@ -915,7 +932,7 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
         attr_set = true;
     }
     if (attn_cluster_bwd_smem(p.Ti, false) > 160 * 1024) return TACO_EINVAL;
-    if (p.s1 == p.S && hipMemsetAsync(p.xchg, 0, (size_t)taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) * sizeof(u64), st) != hipSuccess)
+    if (p.s1 == p.S && hipMemsetAsync(p.xchg, 0, (size_t)(taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) - 16) * sizeof(u64), st) != hipSuccess)
         return TACO_EINVAL;
     AttnCluB q = p;
     q.xcd_local = xcd_local_allowed();
