@@ -123,6 +123,7 @@ class Engine:
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.group_wgrad = os.environ.get('TACO_GROUP_WGRAD', '1') != '0'      # grouped weight / bias gradient launches
         self.fused_highway = os.environ.get('TACO_FUSED_HIGHWAY', '1') != '0'  # four highway layers in one launch per direction
+        self.enc_flush_sites = tuple(int(x) for x in os.environ.get('TACO_ENC_FLUSH', '3'))
         self.post_pipe = os.environ.get('TACO_POST_PIPE', '1') != '0'          # post-net conv bank chunk by chunk behind the decoder
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
         self.world = 1                 # data-parallel replicas (set by train.py / bench.py after init_process_group)
@@ -442,7 +443,10 @@ class Engine:
         """dOUT [M,256] gradient wrt the CBHG output; writes the gradient wrt the CBHG input x into dx [M,cin].
         eager: release the deferred weight-gradient launches to the side stream after every block (encoder: nothing
         latency-bound follows that they could disturb, and held back they would run as a serial tail after the main stream)."""
-        flush = self.flush_side if eager else (lambda: None)
+        # release points: 0 after the highway stack, 1 after proj_2, 2 after proj_1, 3 after the bank (TACO_ENC_FLUSH: which of them the
+        # eager mode uses; default only the last: fewer, larger grouped launches, 7.55 -> 7.52 ms against all four)
+        sites = self.enc_flush_sites if eager else ()
+        flush = lambda k: self.flush_side() if k in sites else None
         M, C, st = N * T, K * 128, self.st
         b = self._bufs
         OUT, RUC = b[sc + '/out'], b[sc + '/ruc']
@@ -473,7 +477,7 @@ class Engine:
                 self.gemm_dw(hw_ins[i - 1], dZs[i - 1], self.G('%s/highway_%d/kernel' % (sc, i)), M, 128, 256)
                 self.colsum(dZs[i - 1], self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
             dhw, other = other, dhw
-            flush()
+            flush(0)
         else:
             for i in range(4, 0, -1):
                 dZ, hw_in = dZs[i - 1], hw_ins[i - 1]
@@ -482,7 +486,7 @@ class Engine:
                 self.colsum(dZ, self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
                 self.gemm_dx(dZ, self.P('%s/highway_%d/kernel' % (sc, i)), other, M, 128, 256, acc=1)
                 dhw, other = other, dhw
-                flush()
+                flush(0)
         if proj[1] != 128:
             dHW0 = self.buf(sc + '/dhw0', M, proj[1])
             self.dense_bwd(b[sc + '/hw0'], dhw, sc + '/highway_dense', M, proj[1], 128, dx=dHW0)
@@ -496,21 +500,21 @@ class Engine:
         self.gemm_dx(dC2, self.P(sc + '/proj_2/kernel'), dY1, M, proj[0], proj[1], T=T, kw=3)
         if after_proj2 is not None:
             after_proj2()              # gradients of the biGRU, the highways and proj_2 are all created: bucket boundary
-        flush()
+        flush(1)
         dC1 = self.buf(sc + '/dc1', M, proj[0])
         self.bn_bwd(sc + '/proj_1', b[sc + '/c1'], dY1, dC1, M, proj[0], T, 0, 1)
         self.gemm_dw(b[sc + '/pool'], dC1, self.G(sc + '/proj_1/kernel'), M, C, proj[0], T=T, kw=3)
         dPL = self.buf(sc + '/dpool', M, C)
         self.gemm_dx(dC1, self.P(sc + '/proj_1/kernel'), dPL, M, C, proj[0], T=T, kw=3)
-        flush()
+        flush(2)
         dB = self.buf(sc + '/dbank', M, C)
         self.bn_bwd(sc + '/conv_bank', b[sc + '/bank'], dPL, dB, M, C, T, 1, 1)
         self.gemm_dw(x, dB, self.G(sc + '/conv_bank/kernel'), M, cin, C, T=T, kw=K, bank=K, ldw=128)
         if bank_dx_later:                  # the caller computes the bank's input gradient piecewise (and adds the residual dHW0)
-            flush()
+            flush(3)
             return dB, dHW0
         self.gemm_dx(dB, self.P(sc + '/conv_bank/kernel'), dx, M, cin, C, T=T, kw=K, bank=K, ldw=128)
-        flush()
+        flush(3)
         lib.taco_add(dx, dHW0, dx, M * cin, 0, st)        # residual connection (modules.py:56)
         return dx
 
