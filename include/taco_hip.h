@@ -61,6 +61,8 @@ int taco_gemm_tn_shift(const float* X, const float* dY, float* dW, int M, int T,
 typedef struct TacoWgrad {
     const float* X; const float* dY; float* dW;
     int M, T, Cin, Cout, kw, bank_K, ldx, lddy, ldw, shift;
+    float* dbias;       /* optional: dbias[c] += sum_m dY[m, c] (bias gradient of a dense layer): summed from the dY tiles the weight-
+                           gradient GEMM stages in LDS anyway, no pass of its own over dY */
 } TacoWgrad;
 int taco_wgrad_group(const TacoWgrad* items, int count, hipStream_t stream);
 /* the same for bias gradients: out_i[c] += sum_m x_i[m, c] for `count` tensors in one launch (HOST array) */

@@ -31,6 +31,7 @@ struct ConvGemm {
     int accumulate;     // NN/NT: C += result
     int splitk;         // TN: reduction split
     int shift0;         // TN: extra row shift of X (dW of recurrent weights: X = H shifted by one step)
+    float* dbias;       // TN (dense problems, v2 64x64x32 kernel): optional bias gradient dbias[n] += sum_m dY[m, n], summed from the dY tiles in LDS
     double* bn_stat;    // NN: optional batch-norm sums of the OUTPUT (after bias + activation): TACO_BN_REPL replicas of [sum | sum of squares | -] x N
     int rb_len, rb_stride, rb_off;   // NN/NT row blocking: logical row m -> physical row (m / rb_len) * rb_stride + rb_off + m % rb_len
                                      // (a chunk of steps [s0, s0+rb_len) of [N,S,*] tensors seen as one [N*rb_len, *] matrix); 0 = identity
@@ -942,6 +943,16 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
     MmaKs<BM, BN, BK> mm;
     mm.init(wm, wn, lane);
+    // bias gradient of a dense layer = column sums of dY: the workgroups of the first X-column tile add up the dY tiles they stage
+    // anyway (thread = column tid % BN, rows (tid / BN) * (BK * BN / 256) ... of every tile; rows beyond M were loaded as zeros)
+    const bool do_bias = p.dbias != nullptr && bx == 0 && seg == 0;
+    float bsum = 0.f;
+    auto bias_tile = [&](const float* Bs) {
+        constexpr int RPT = BK * BN / 256;           // rows per thread
+        const int col = tid % BN, r0 = (tid / BN) * RPT;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) bsum += Bs[(r0 + k) * BN + col];
+    };
 
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
@@ -955,6 +966,7 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
             const bool more = issued < nsteps;
             if (more) issue(smem[(u + STAGES - 1) % STAGES]);
             mm.run(smem[u], smem[u] + ASZ, acc);
+            if (do_bias) bias_tile(smem[u] + ASZ);
             if (STAGES == 3 && more) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
             __syncthreads();
         }
@@ -962,12 +974,15 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
     const int rem = nsteps - ngroups * STAGES;
     if (rem >= 1) {
         mm.run(smem[0], smem[0] + ASZ, acc);
+        if (do_bias) bias_tile(smem[0] + ASZ);
         if (STAGES == 3 && rem == 2) {
             wait_vmcnt<0>();
             __syncthreads();
             mm.run(smem[1], smem[1] + ASZ, acc);
+            if (do_bias) bias_tile(smem[1] + ASZ);
         }
     }
+    if (do_bias && n0 + tid % BN < p.N) atomicAdd(p.dbias + n0 + tid % BN, bsum);
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int ni = 0; ni < BN / 64; ++ni) {
@@ -1260,7 +1275,7 @@ extern "C" int taco_conv_rows_bwd_data(const float* dY, const float* W, float* d
 // plans one weight-gradient problem: fills p and the launch grid; cfg: 0 = v2 64x64x32 (3 stages; the grouped kernel's
 // configuration), 1 = v2 64x64x32 2 stages (short loops), 2 = v2 128x128x16, 3 = v1 64, 4 = v1 128
 static int plan_bwd_weight(ConvGemm& p, dim3& g, int& cfg, const float* X, const float* dY, float* dW, int M, int T, int Cin,
-                           int Cout, int kw, int bank_K, int ldx, int lddy, int ldw, int shift0, int wgs_target) {
+                           int Cout, int kw, int bank_K, int ldx, int lddy, int ldw, int shift0, int wgs_target, float* dbias = nullptr) {
     // dW must be zero-initialised (or hold a running sum): partial sums are atomically ADDED.
     p = ConvGemm{};
     p.shift0 = shift0;
@@ -1290,6 +1305,7 @@ static int plan_bwd_weight(ConvGemm& p, dim3& g, int& cfg, const float* X, const
     // v2 needs 31-bit byte offsets into X (plus the shifted rows) and dY
     const bool v2 = !force_v1 && ((long)M + 64) * ldx * 4 < (1L << 31) && ((long)M + 64) * lddy * 4 < (1L << 31);
     cfg = !v2 ? (big ? 4 : 3) : big ? 2 : (cdiv(ktiles, splitk) <= 8 ? 1 : 0);
+    p.dbias = (cfg <= 1 && kw == 1 && bank_K == 0) ? dbias : nullptr;      // fused bias gradient: dense problems on the 64x64x32 v2 kernel
     return TACO_OK;
 }
 
@@ -1344,7 +1360,9 @@ extern "C" int taco_wgrad_group(const TacoWgrad* items, int count, hipStream_t s
         const TacoWgrad& it = items[i];
         ConvGemm p; dim3 g; int cfg;
         if (int e = plan_bwd_weight(p, g, cfg, it.X, it.dY, it.dW, it.M, it.T, it.Cin, it.Cout, it.kw, it.bank_K, it.ldx, it.lddy,
-                                    it.ldw, it.shift, grp_wgs)) return e;
+                                    it.ldw, it.shift, grp_wgs, it.dbias)) return e;
+        if (it.dbias && !p.dbias)            // a problem whose bias gradient cannot ride on its GEMM: column sums in a launch of their own
+            if (int e = taco_col_sum(it.dY, it.lddy, it.dbias, it.M, it.Cout, stream)) return e;
         if (cfg > 1 || g.x > 65535 || g.y > 65535) { launch_bwd_weight(p, g, cfg, stream); continue; }
         pl[n].p = p; pl[n].g = g;
         pl[n].work = (double)g.x * g.y * g.z * cdiv(cdiv(it.M, 32), p.splitk);

@@ -18,7 +18,8 @@ from .params import ParamLayout, init_named
 
 class TacoWgrad(ctypes.Structure):          # include/taco_hip.h
     _fields_ = [('X', ctypes.c_void_p), ('dY', ctypes.c_void_p), ('dW', ctypes.c_void_p)] + \
-               [(n, ctypes.c_int) for n in ('M', 'T', 'Cin', 'Cout', 'kw', 'bank_K', 'ldx', 'lddy', 'ldw', 'shift')]
+               [(n, ctypes.c_int) for n in ('M', 'T', 'Cin', 'Cout', 'kw', 'bank_K', 'ldx', 'lddy', 'ldw', 'shift')] + \
+               [('dbias', ctypes.c_void_p)]
 
 
 class TacoColSum(ctypes.Structure):
@@ -123,6 +124,7 @@ class Engine:
         self.overlap_wgrad = os.environ.get('TACO_OVERLAP_WGRAD', '1') != '0'
         self.group_wgrad = os.environ.get('TACO_GROUP_WGRAD', '1') != '0'      # grouped weight / bias gradient launches
         self.fused_highway = os.environ.get('TACO_FUSED_HIGHWAY', '1') != '0'  # four highway layers in one launch per direction
+        self.fuse_bias_grad = os.environ.get('TACO_FUSE_BIAS_GRAD', '1') != '0'   # dense bias gradients ride on the weight-gradient GEMMs
         self.enc_flush_sites = tuple(int(x) for x in os.environ.get('TACO_ENC_FLUSH', '3'))
         self.post_pipe = os.environ.get('TACO_POST_PIPE', '1') != '0'          # post-net conv bank chunk by chunk behind the decoder
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
@@ -253,9 +255,10 @@ class Engine:
         if dw:
             arr = (TacoWgrad * len(dw))()
             fl = 0.0
-            for a, (_, X, dY, dW, M, T, Cin, Cout, kw, bank, ldx, lddy, ldw, shift, flops) in zip(arr, dw):
+            for a, (_, X, dY, dW, M, T, Cin, Cout, kw, bank, ldx, lddy, ldw, shift, flops, *dbias) in zip(arr, dw):
                 a.X, a.dY, a.dW = X.data_ptr(), dY.data_ptr(), dW.data_ptr()
                 a.M, a.T, a.Cin, a.Cout, a.kw, a.bank_K, a.ldx, a.lddy, a.ldw, a.shift = M, T, Cin, Cout, kw, bank, ldx, lddy, ldw, shift
+                a.dbias = dbias[0].data_ptr() if dbias else None       # bias gradient riding on this GEMM (colsum())
                 fl += flops
             if self.group_wgrad:
                 self._timed('dW GEMM (conv_gemm_tn2_group)', fl, lambda: lib.taco_wgrad_group(ctypes.addressof(arr), len(dw), self.st))
@@ -265,6 +268,8 @@ class Engine:
                         lib.taco_gemm_tn_shift(a.X, a.dY, a.dW, a.M, a.T, a.Cin, a.Cout, a.ldx, a.lddy, a.ldw, a.shift, self.st)
                     else:
                         lib.taco_conv_gemm_bwd_weight(a.X, a.dY, a.dW, a.M, a.T, a.Cin, a.Cout, a.kw, a.bank_K, a.ldx, a.lddy, a.ldw, self.st)
+                    if a.dbias:
+                        lib.taco_col_sum(a.dY, a.lddy, a.dbias, a.M, a.Cout, self.st)
         if cs:
             arr = (TacoColSum * len(cs))()
             for a, (_, x, ldx, out, M, C) in zip(arr, cs):
@@ -341,6 +346,16 @@ class Engine:
         self._side(('dw', X, dY, dW, M, T, K, N, 1, 0, ldx, lddy, ldw, shift, 2.0 * M * K * N))
 
     def colsum(self, x, out, M, C, ldx=None):
+        """out[c] += sum_m x[m, c] (bias gradient).  When the weight-gradient GEMM of the same dense layer is still queued (same dY,
+        same rows, kw = 1), the sums ride on it: its workgroups add up the dY tiles they stage in LDS anyway (TacoWgrad.dbias) and
+        no pass of its own reads dY again."""
+        if self._side_active and self.group_wgrad and self.fuse_bias_grad:
+            for i in range(len(self._deferred) - 1, -1, -1):
+                it = self._deferred[i]
+                if (isinstance(it, tuple) and it[0] == 'dw' and len(it) == 15 and it[2].data_ptr() == x.data_ptr() and it[4] == M
+                        and it[8] == 1 and it[9] == 0 and 0 <= C - it[7] < 4 and it[11] == (ldx or x.stride(-2))):
+                    self._deferred[i] = it + (out,)
+                    return
         self._side(('cs', x, ldx or x.stride(-2), out, M, C))
 
     def dense_fwd(self, x, scope, y, M, cin, cout, act=0):

@@ -424,13 +424,20 @@ def test_grouped_weight_and_bias_gradients():
     for i in range(30):
         add(256 + 64 * (i % 5), 32, 64 + 4 * i, 128 + 4 * (i % 7))
     arr = (TacoWgrad * len(probs))()
-    for a, (x, dy, dw, M, T, cin, cout, kw, bank, shift, _) in zip(arr, probs):
+    dbs = []            # bias gradients riding on the weight-gradient GEMMs (every second problem asks for one, also conv / bank ones,
+                        # whose sums the library takes in a launch of their own)
+    for k, (a, (x, dy, dw, M, T, cin, cout, kw, bank, shift, _)) in enumerate(zip(arr, probs)):
         a.X, a.dY, a.dW = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
         a.M, a.T, a.Cin, a.Cout, a.kw, a.bank_K, a.ldx, a.lddy, a.ldw, a.shift = M, T, cin, cout, kw, bank, cin, dy.shape[1], cout, shift
+        db = torch.zeros(dy.shape[1], device=dev) if (k % 2 == 0 and not bank) else None
+        dbs.append(db)
+        a.dbias = db.data_ptr() if db is not None else None
     lib.taco_wgrad_group(ctypes.addressof(arr), len(probs), stream())
     torch.cuda.synchronize()
-    for (x, dy, dw, M, T, cin, cout, kw, bank, shift, ref) in probs:
+    for db, (x, dy, dw, M, T, cin, cout, kw, bank, shift, ref) in zip(dbs, probs):
         assert rel(dw.cpu().numpy(), ref.cpu().numpy()) < 1e-5, (M, T, cin, cout, kw, bank, shift)
+        if db is not None:
+            assert rel(db.cpu().numpy(), dy.double().sum(0).cpu().numpy()) < 1e-5, (M, T, cin, cout, kw, shift)
     cs = (TacoColSum * len(probs))()
     outs = []
     for a, (x, dy, *_r) in zip(cs, probs):
