@@ -260,8 +260,19 @@ def main():
     # process has been submitting for SETTLE seconds keep it out of the timed region.
     settle = float(os.environ.get('TACO_BENCH_SETTLE', '2.5'))
     i_extra = 0
-    while time.perf_counter() - t_start < settle:
-        step(i_extra); i_extra += 1
+    if world > 1:
+        # every rank must run the SAME number of steps (each contains the gradient exchange): rank 0's clock decides, in rounds of 25
+        import torch.distributed as dist
+        while True:
+            more = torch.tensor([1 if (time.perf_counter() - t_start < settle) else 0], device=dev, dtype=torch.int32)
+            dist.broadcast(more, src=0)
+            if int(more.item()) == 0:
+                break
+            for _ in range(25):
+                step(i_extra); i_extra += 1
+    else:
+        while time.perf_counter() - t_start < settle:
+            step(i_extra); i_extra += 1
     torch.cuda.synchronize()
 
     def barrier():
