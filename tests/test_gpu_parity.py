@@ -382,6 +382,41 @@ def test_conv_bank(N, T, cin, K):
     assert rel(dw.cpu().numpy(), torch.cat([w.grad for w in w64], 0).cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('N,T,cin,K', [(3, 50, 80, 8), (32, 96, 80, 8)])
+def test_conv_bank_by_frame_ranges_and_epilogue_bn_sums(N, T, cin, K):
+    """The pieces the post-net bank is computed in behind the decoder pipeline (taco_conv_rows_fwd / taco_conv_rows_bwd_data over frame
+    ranges of every sequence) against the whole-tensor launches: forward bit for bit, input gradient to accumulation-order noise (the
+    pieces are split over the taps with atomic adds), batch-norm sums from the GEMM epilogues against float64 sums."""
+    from tacotron_multispeaker_amd._lib import lib, stream
+    dev, M, C = 'cuda', N * T, K * 128
+    torch.manual_seed(K + N)
+    x = torch.randn(M, cin, device=dev)
+    wp = torch.randn(K * (K + 1) // 2, cin, 128, device=dev) / np.sqrt(cin * 4)
+    b = torch.randn(C, device=dev)
+    y_full, y_rows = torch.empty(M, C, device=dev), torch.full((M, C), 7.0, device=dev)
+    st_full, st_rows = torch.zeros(24 * C, dtype=torch.float64, device=dev), torch.zeros(24 * C, dtype=torch.float64, device=dev)
+    lib.taco_conv_gemm_bn_fwd(x, wp, b, y_full, M, T, cin, C, K, K, cin, 128, C, 1, st_full, stream())
+    cuts = [0, T // 3 - 4, 2 * T // 3 - 4, T]                      # like the engine: a piece ends K // 2 frames short of its chunk
+    for t0, t1 in zip(cuts[:-1], cuts[1:]):
+        lib.taco_conv_rows_fwd(x, wp, b, y_rows, N, T, t0, t1, cin, C, K, K, cin, 128, C, 1, st_rows, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y_full, y_rows)
+    y64 = y_full.double()
+    for st in (st_full, st_rows):
+        sums = st.view(8, 3, C).sum(0)
+        assert rel(sums[0].cpu().numpy(), y64.sum(0).cpu().numpy()) < 1e-6
+        assert rel(sums[1].cpu().numpy(), (y64 * y64).sum(0).cpu().numpy()) < 1e-6
+    dy = torch.randn(M, C, device=dev)
+    dx_full = torch.empty(M, cin, device=dev)
+    lib.taco_conv_gemm_bwd_data(dy, wp, dx_full, M, T, cin, C, K, K, C, 128, cin, 0, stream())
+    init = torch.randn(M, cin, device=dev)
+    dx_rows = init.clone()
+    for t0, t1 in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        lib.taco_conv_rows_bwd_data(dy, wp, dx_rows, N, T, t0, t1, cin, C, K, K, C, 128, cin, 1, stream())
+    torch.cuda.synchronize()
+    assert rel((dx_rows - init).cpu().numpy(), dx_full.cpu().numpy()) < 1e-5
+
+
 def test_grouped_weight_and_bias_gradients():
     """taco_wgrad_group / taco_col_sum_group: many independent weight-gradient problems (dense, conv k=3, conv bank, shifted
     recurrent-weight form, ragged shapes) in ONE launch against float64 references; more problems than one group holds."""
