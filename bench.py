@@ -22,6 +22,14 @@ Prints ONE JSON line (rank 0).  Besides the contract fields:
   cpu_baseline         the CPU stand-in (oracle/tacotron_torch.py, fp32, same step) on this box's host cores (rank 0, N=1 only);
                        TF-1 itself cannot run anywhere in this pipeline (SURVEY.md 8(c,d))
   allreduce_exposed_ms (N > 1) time the optimizer's stream waits for the gradient exchange after backward has finished
+  train_loop           (N = 1) the loop train.py actually runs -- Tacotron.submit_step()/collect() on feeder handles: numpy batches
+                       -> stager thread -> pinned buffers -> device, one 128-byte status read-back per step, one step in flight:
+                       train_loop_ms_per_step (same C2 batches), ms_per_step_synced (run_step(): the host waits for every step
+                       before it enqueues the next), train_loop_shapes (a cycle of 5 different (T_in, T_out) shapes, beside the
+                       back-to-back time of the same cycle).  `value` / ms_per_step remain the back-to-back device-resident loop.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run as a child process,
+before anything touches the GPU) and exits with its code.
 """
 import argparse
 import json
@@ -170,6 +178,71 @@ def parity_vs_oracle(eng, P, batch, r, id_num):
     return out
 
 
+def train_loop_legs(model, eng, cfg, steps, warmup):
+    """The step loop of train.py (reference train.py:139-152) on synthetic feeder batches; see the module docstring."""
+    N, Ti, To, r, id_num = cfg
+
+    def np_pool(shapes, seed0):
+        return [synth.synth_batch(N, ti, to, r, seed=seed0 + i, id_num=id_num) for i, (ti, to) in enumerate(shapes)]
+
+    def run(pool, pipelined, K, W):
+        feeder = synth.SyntheticFeeder(pool)
+        model.attach_feeder(feeder)
+        feeder.start_in_session(None)
+        inflight, done, t0, frames = [], 0, None, 0
+        try:
+            while done < W + K:
+                if pipelined:
+                    while len(inflight) < 2 and done + len(inflight) < W + K:
+                        inflight.append(model.submit_step())
+                    out = model.collect(inflight.pop(0))
+                else:
+                    out = model.run_step()
+                assert out is not None
+                done += 1
+                if done == W:
+                    t0 = time.perf_counter()
+                elif done > W:
+                    frames += pool[(done - 1) % len(pool)]['mel_targets'].shape[1] * N
+        finally:
+            dt = time.perf_counter() - t0
+            st = model._stager
+            host_copy_ms = st.host_copy_s / max(st.batches, 1) * 1e3
+            feeder.stop()
+            model.stop()
+            torch.cuda.synchronize()
+        return dt / K * 1e3, frames / dt, host_copy_ms
+
+    out = {}
+    same = np_pool([(Ti, To)] * 4, 4321)
+    ms, fps, hc = run(same, True, steps, warmup)
+    out['train_loop_ms_per_step'] = ms
+    out['train_loop_mel_frames_per_sec'] = fps
+    out['train_loop_host_copy_ms_per_batch'] = hc
+    ms_s, _, _ = run(same, False, steps, warmup)
+    out['ms_per_step_synced'] = ms_s
+    # five shapes a length-bucketed LJSpeech feeder would hand over in a row (T_out multiples of r)
+    rr = lambda x: max(r, int(round(x / r)) * r)
+    shapes = [(Ti, To), (max(8, Ti * 7 // 8), rr(To * 0.875)), (max(8, Ti * 3 // 4), rr(To * 0.75)), (max(8, Ti * 15 // 16), rr(To * 0.95)),
+              (max(8, Ti * 5 // 8), rr(To * 0.66))]
+    pool = np_pool(shapes, 8765)
+    ms_v, fps_v, _ = run(pool, True, steps, max(warmup, 2 * len(shapes)))
+    # the same cycle back to back on device-resident batches (no feeder, no read-back)
+    dev_pool = [synth.batch_to_device(b, eng.dev) for b in pool]
+    for i in range(2 * len(pool)):
+        eng.train_step(*dev_pool[i % len(pool)])
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(steps):
+        eng.train_step(*dev_pool[i % len(pool)])
+    torch.cuda.synchronize()
+    b2b = (time.perf_counter() - t) / steps * 1e3
+    out['train_loop_shapes'] = dict(shapes=shapes, ms_per_step=ms_v, mel_frames_per_sec=fps_v, back_to_back_ms_per_step=b2b)
+    out['train_loop_note'] = ('train.py loop: feeder handles -> stager thread -> pinned ring -> device ring, Tacotron.submit_step/collect, '
+                              'one 128-byte status copy + one event wait per step, one step in flight; synced = run_step() every step')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -179,9 +252,21 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-families', action='store_true', help='skip the extra instrumented steps (rocprofv3 runs)')
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C2x', 'C4', 'C5', 'C2x2', 'C2x4'])   # C2xK: K times the C2 batch per GPU
+    ap.add_argument('--no-train-loop', action='store_true', help='skip the train.py-loop legs')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started as plain `python bench.py --gpus N`: launch the N ranks as a CHILD process before anything touches the GPU
+        # (never an exec) and leave with its exit code
+        import subprocess
+        port = os.environ.get('MASTER_PORT', '29531')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if a.gpus != world:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d ...)'
+                 % (a.gpus, world, a.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
@@ -198,7 +283,19 @@ def main():
     N, Ti, To, r, id_num = cfg
     from tacotron_multispeaker_amd.params import init_named, ParamLayout
     P = init_named(ParamLayout(id_num=id_num, r=r), 0)          # identical weights on every replica (RandomState(0))
-    eng = Engine(r=r, id_num=id_num, named_params=P, device=dev)
+    # the engine is built through the reference's construction API on feeder handles (the train-loop legs drive it that way); the
+    # headline loop below calls the same engine directly on device-resident batches
+    import hparams as H
+    from models import create_model
+    from models.tacotron import GlobalStep
+    H.hparams.parse('outputs_per_step=%d,batch_size=%d' % (r, N))
+    handles = synth.SyntheticFeeder([])
+    model = create_model('tacotron', H.hparams)
+    model.initialize(handles.inputs, handles.input_lengths, handles.mel_targets, handles.linear_targets, identities=handles.identities,
+                     id_num=id_num, named_params=P, device=dev)
+    model.add_loss()
+    model.add_optimizer(GlobalStep())
+    eng = model.engine
     eng.world = world
     pool = [synth.batch_to_device(synth.synth_batch(N, Ti, To, r, seed=1234 + rank * 1000 + i, id_num=id_num), dev) for i in range(4)]
     static = [t.clone() if t is not None else None for t in pool[0]]
@@ -307,7 +404,8 @@ def main():
         dt = float(tt.item())
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     loss = eng.loss_values()[0]
-    err = int(eng.err.item())
+    errw = [int(x) for x in eng.err.cpu().tolist()]
+    err = errw[0]
     exposed = None
     if world > 1:
         exposed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in eng.exposed_events[-a.steps:]]))
@@ -330,6 +428,9 @@ def main():
                                    'full training step (fwd+bwd+allreduce+clipped Adam)' % (a.config, N, Ti, To, r, id_num),
                        'global_batch': N * world, 'parallelism': 'dp%d' % world, 'hip_graph': use_graph},
             'loss_after': loss, 'cluster_handoff_timeouts': err,
+            # placement of the persistent clusters over every launch so far: clusters whose members were NOT on one XCD keep the
+            # agent-scope granule form (slower, same results)
+            'cluster_xcd_fallbacks': errw[1], 'cluster_placements_checked': errw[2],
             'step_roofline': {'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS,
                               'unit': 'TFLOP/s', 'frac': fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                               'flops_per_step': fl, 'hbm': {'achieved': by / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
@@ -354,6 +455,8 @@ def main():
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         else:
             out['cpu_baseline'] = None
+        if world == 1 and not a.no_train_loop:
+            out.update(train_loop_legs(model, eng, cfg, a.steps, a.warmup))
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -172,15 +172,20 @@ int taco_attn_cluster_bwd_variant(int N, int Ti);
 int taco_attn_cluster_fwd_variant(int N, int Ti);
 /* residual decoder GRU(256), whole recurrence in one persistent cluster launch (csrc/gru256.hip); hoisted input
  * projection xp [N,S,768]; d = res + h when d != NULL.  xchg: >= ceil(N/2)*6*256 8-byte granule slots of scratch,
- * err: device int set to 1 if a bounded spin ever times out (results are then invalid).  N <= 128.
+ * err: device int[4]: [0] set to 1 if a bounded spin ever times out (results are then invalid), [1] / [2] placement statistics
+ * (clusters on the agent-scope fallback / clusters checked, see TACO_AP_ERR).  N <= 128.
  * [s0, s1): step range of this launch -- the recurrence may be cut into chunks launched in order (forward: ascending,
  * backward: descending) so that chunks of different recurrences can be pipelined on different streams; the state passes
- * through h (forward) and carry [N,256] (backward). */
+ * through h (forward) and carry [N,256] (backward).
+ * isolate_lds_bytes: unused dynamic LDS per workgroup (0 = none, at most 155000): with ~150 KB a workgroup owns its CU and no GEMM
+ * workgroup shares its SIMDs; the caller decides (it knows the batch, the other persistent launches in flight and whether
+ * collective kernels need room on those CUs). */
 int taco_gru256_seq_fwd(const float* xp, const float* whg, const float* whc, const float* res, float* r, float* u, float* c,
-                        float* rh, float* h, float* d, void* xchg, int* err, int N, int S, int s0, int s1, hipStream_t stream);
+                        float* rh, float* h, float* d, void* xchg, int* err, int N, int S, int s0, int s1, int isolate_lds_bytes,
+                        hipStream_t stream);
 int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, const float* r, const float* u, const float* c,
                         const float* h, float* dxp, float* carry, void* xchg, int* err, int N, int S, int s0, int s1,
-                        hipStream_t stream);
+                        int isolate_lds_bytes, hipStream_t stream);
 
 /* ---- optimizer: tf.clip_by_global_norm + tf.train.AdamOptimizer + Noam lr + BN UPDATE_OPS (tacotron.py:174-202) -- */
 int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream);
@@ -194,6 +199,14 @@ int taco_adam_step(float* params, const float* grads, float* m, float* v, long n
                    float grad_scale, float* info3, const int* err, hipStream_t stream);
 int taco_bn_ema(float* moving, const float* batch, int n, float momentum, int* global_step, const int* err, hipStream_t stream);
 int taco_step_inc(int* global_step, const int* err, hipStream_t stream);
+/* What the step loop reads back (reference train.py:142-152 fetches global_step, loss, loss_regularity; :23-36 the summary
+ * scalars), packed into out16 = 16 doubles: 0 mel L1 sum, 1 linear L1 sum over all columns, 2 over the priority columns (the sums2
+ * replicas of taco_l1_loss added up), 3 loss_regularity, 4 global norm before the clip, 5 learning rate, 6 clip factor,
+ * 7 global_step, 8 err4[0] (hand-off timeout), 9 err4[1] (clusters on the agent-scope fallback), 10 err4[2] (clusters that ran the
+ * placement check), rest 0.  loss_sums = mel sums2 followed by the linear sums2 (2 * 2 * TACO_L1_REPL doubles); optional inputs may
+ * be NULL.  One launch + one 128-byte device-to-host copy behind an event replace the blocking per-value reads. */
+int taco_step_status(const double* loss_sums, const double* reg_sum, const float* info3, const int* err4, const int* global_step,
+                     double* out16, hipStream_t stream);
 int taco_scale(float* x, long n, float s, hipStream_t stream);
 /* zero-fill (one memset node): bytes and p must be multiples of 16 */
 int taco_zero(void* p, size_t bytes, hipStream_t stream);
@@ -226,7 +239,8 @@ enum TacoAttnPtr {
     TACO_AP_DA,        /* scratch [N,Ti] */
     TACO_AP_DHT, TACO_AP_DHPART, TACO_AP_DHCARRY, TACO_AP_DCTX, TACO_AP_DCTXCARRY, /* scratch [N,256] each */
     TACO_AP_XCHG,      /* optional: >= taco_attn_cluster_xchg_slots(N,Ti) 8-byte granule slots (enables the cluster path) */
-    TACO_AP_ERR,       /* optional: device int, set to 1 if a bounded hand-off spin timed out */
+    TACO_AP_ERR,       /* optional: device int[4]: [0] set to 1 if a bounded hand-off spin timed out, [1] clusters that kept the
+                          agent-scope granule form although the L2-local form was allowed, [2] clusters that ran the placement check */
     TACO_AP_DE,        /* cluster bwd: out, softmax-input gradients de_s[t]           [N,S,Ti] */
     TACO_AP_DCTXS,     /* cluster bwd: out, total context gradients per step          [N,S,256] */
     TACO_AP_DAEXT,     /* optional in: extra gradient wrt the alignments (taco_align_regularity) [N,S,Ti]; may be NULL */

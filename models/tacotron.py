@@ -13,6 +13,9 @@ them) or the `.inputs ... .identities` handles of datasets.datafeeder_npy.DataFe
 the reference): then every run_step() dequeues the next batch.  All arithmetic runs in the HIP kernels of
 tacotron_multispeaker_amd (no TensorFlow, no torch compute, no CPU fallback).
 """
+import queue
+import threading
+
 import numpy as np
 import torch
 
@@ -38,6 +41,10 @@ class Tacotron():
         self._feeder = None
         self._static = None
         self._global_step = None
+        self._stager = None
+        self._pending = None
+        self._status_ring = None
+        self._tickets = 0
 
     # ------------------------------------------------------------------------------------------------
     def initialize(self, inputs, input_lengths, mel_targets=None, linear_targets=None, identities=None, id_num=0,
@@ -86,48 +93,16 @@ class Tacotron():
         return t.to(device=self.engine.dev, dtype=dtype).contiguous()
 
     # ---- host -> device staging for the feeder path -------------------------------------------
-    # A batch is ~91 MB at C2 (linear targets 84 MB): it is copied into PINNED host buffers and sent with an
-    # asynchronous copy on a dedicated stream while the previous step is still computing (2-deep), so PCIe time
-    # (~1.5 ms at Gen5 x16) is off the step's critical path.
-    def _stage(self, batch):
-        dev = self.engine.dev
-        if not hasattr(self, '_copy_stream'):
-            self._copy_stream = torch.cuda.Stream(device=dev)
-            self._pinned = [dict(), dict()]
-            self._stage_idx = 0
-        slot = self._pinned[self._stage_idx]
-        self._stage_idx ^= 1
-        names = ('inputs', 'input_lengths', 'mel_targets', 'linear_targets', 'wavs', 'identities')
-        dtypes = (torch.int32, torch.int32, torch.float32, torch.float32, None, torch.int32)
-        out = []
-        with torch.cuda.stream(self._copy_stream):
-            for name, dt, arr in zip(names, dtypes, batch):
-                if dt is None or (name == 'identities' and not self._id_num):
-                    out.append(None)
-                    continue
-                src = torch.as_tensor(np.ascontiguousarray(arr)).to(dt)
-                flat = slot.get(name)          # pinned capacity only grows (batch shapes change every step with the real feeder)
-                if flat is None or flat.numel() < src.numel():
-                    flat = torch.empty(max(src.numel(), 1), dtype=dt).pin_memory()
-                    slot[name] = flat
-                buf = flat[:src.numel()].view(src.shape)
-                buf.copy_(src)
-                out.append(buf.to(dev, non_blocking=True))
-            ev = torch.cuda.Event()
-            ev.record(self._copy_stream)
-        return out, ev, batch
-
+    # A batch is ~91 MB at C2 (linear targets 84 MB).  A stager thread (_Stager below) takes the feeder's numpy batches, copies
+    # them into a ring of PINNED host buffers (the copy releases the GIL) and starts the asynchronous host-to-device copies on a
+    # copy stream into a ring of device buffers, up to two batches ahead of the running step: neither the host copy nor the PCIe
+    # time (~1.5 ms at Gen5 x16) is on the step's critical path, and no buffer is allocated after the largest shape has been seen.
     def _next_staged(self):
-        """Returns the staged batch for this step and starts staging the following one."""
-        if getattr(self, '_staged', None) is None:
-            b = self._feeder.dequeue()
-            if b is None:
-                return None
-            self._staged = self._stage(b)
-        cur = self._staged
-        nxt = self._feeder.dequeue(timeout=0.001) if self._feeder._queue.qsize() > 0 else None
-        self._staged = self._stage(nxt) if nxt is not None else None
-        return cur
+        """(device tensors, ready event, numpy batch, ring slot) of the next batch; None once the feeder has stopped."""
+        if self._stager is None:
+            self._stager = _Stager(self._feeder, self.engine.dev, bool(self._id_num))
+            self._stager.start()
+        return self._stager.get()
 
     def _set_batch(self, inputs, input_lengths, mel_targets, linear_targets, identities):
         hp = self._hparams
@@ -168,13 +143,35 @@ class Tacotron():
     # ------------------------------------------------------------------------------------------------
     def run_step(self):
         """One optimizer step == sess.run([global_step, loss, optimize, loss_regularity]) (train.py:142-146).
-        Returns (global_step after the step, loss, None, loss_regularity)."""
+        Returns (global_step after the step, loss, None, loss_regularity).  = collect(submit_step()): the host waits ONCE, for
+        the one 128-byte status copy of the step."""
+        t = self.submit_step()
+        return None if t is None else self.collect(t)
+
+    STATUS_RING = 4            # status slots = the most tickets that may be outstanding
+
+    def next_batch_ready(self):
+        """True when submit_step() has a batch to run (blocks until the stager has one or the feeder has stopped).  Data-parallel
+        drivers call it on every rank and agree on the answers BEFORE any rank enqueues the step and its gradient all-reduce."""
+        if self._feeder is None:
+            return True
+        if self._pending is None:
+            self._pending = self._next_staged()
+        return self._pending is not None
+
+    def submit_step(self, snapshot=False):
+        """Enqueue one training step WITHOUT waiting for it and return a ticket for collect().  A driver that keeps one ticket
+        outstanding (train.py: submit step k+1, then collect step k) never lets the GPU run dry while the host enqueues: the
+        step's scalars travel in one asynchronous copy behind an event (Engine.status_async).  snapshot=True also clones the
+        model state right behind the step (stream-ordered, device to device), so a checkpoint of exactly this step can be written
+        after later steps have been submitted (Ticket.state_dict()).  Returns None once the feeder has stopped."""
         e = self.engine
+        slot = batch = None
         if self._feeder is not None:
-            staged = self._next_staged()
-            if staged is None:
+            if not self.next_batch_ready():
                 return None
-            dev_t, ev, batch = staged
+            staged, self._pending = self._pending, None
+            dev_t, ev, batch, slot = staged
             torch.cuda.current_stream().wait_event(ev)
             hp = self._hparams
             if dev_t[2].shape[1] // hp.outputs_per_step > hp.max_iters:
@@ -184,18 +181,58 @@ class Tacotron():
         s = self._static
         e.train_step(s[0], s[1], s[2], s[3], s[4])
         self.mel_outputs, self.linear_outputs, self.alignments = e.mel_outputs, e.linear_outputs, e.alignments
-        self.loss, self.mel_loss, self.linear_loss = e.loss_values()
-        self.loss_regularity = e.loss_regularity
-        e.check_errors()        # the stream is idle after the loss read-back: a timed-out cluster hand-off must not train on
-        step = int(e.global_step.item())
-        self.learning_rate = float(e.info[1].item())
-        return step, self.loss, None, self.loss_regularity
+        if self._status_ring is None:
+            self._status_ring = [torch.zeros(16, dtype=torch.float64).pin_memory() for _ in range(self.STATUS_RING)]
+        pinned = self._status_ring[self._tickets % self.STATUS_RING]
+        self._tickets += 1
+        done = e.status_async(pinned)
+        snap = self._snapshot() if snapshot else None
+        if slot is not None:
+            self._stager.release(slot, done)       # the device buffers of this batch may be refilled once the step has run
+        return Ticket(self, done, pinned, e.dims, batch, snap)
 
-    # checkpoint in the build's own format (TF checkpoints cannot be read without TF)
-    def state_dict(self):
+    def collect(self, ticket):
+        """Wait for a submitted step (the only host wait of the step) -> (global_step, loss, None, loss_regularity); also sets
+        .loss .mel_loss .linear_loss .loss_regularity .learning_rate .max_gradient_norm like the reference's fetches/summaries.
+        Raises if a persistent cluster kernel reported a hand-off timeout (the optimizer skipped that step on the device)."""
+        ticket.done.synchronize()
+        st = self.engine.status_decode(ticket.pinned, ticket.dims)
+        ticket.status = st
+        if st['err'] != 0:
+            raise RuntimeError('persistent cluster kernel reported a hand-off timeout; results are invalid')
+        self.loss, self.mel_loss, self.linear_loss = st['loss'], st['mel_loss'], st['linear_loss']
+        self.loss_regularity = st['loss_regularity']
+        self.engine.loss_regularity = st['loss_regularity']
+        self.learning_rate = st['learning_rate']
+        self.max_gradient_norm = st['global_norm']
+        self.last_status = st
+        return st['global_step'], st['loss'], None, st['loss_regularity']
+
+    def attach_feeder(self, feeder):
+        """Switch to another feeder object (anything with DataFeeder's dequeue()); the stager restarts on it."""
+        self.stop()
+        self._feeder, self._stager, self._pending = feeder, None, None
+
+    def stop(self):
+        """ends the stager thread (train.py calls it when the loop ends)"""
+        if self._stager is not None:
+            self._stager.stop()
+
+    # checkpoint in the build's own format (TF checkpoints cannot be read without TF; SURVEY.md 8(f) row f2): the flat buffers
+    # plus their NAMED layout -- every entry's name (the reference's variable scopes under ParamLayout.TF_SCOPE, e.g.
+    # 'model/inference/embedding_id', the one name the reference itself reads back, synthesizer.py:25), offset and shape -- so a
+    # file describes itself and a file written by a different layout is refused.
+    def _layout_dict(self):
+        L = self.engine.L
+        return dict(id_num=self._id_num, r=self.engine.r, signature=L.signature(), tf_scope=L.TF_SCOPE, entries=L.describe())
+
+    def _snapshot(self):
         e = self.engine
-        return dict(params=e.params.cpu(), m=e.m.cpu(), v=e.v.cpu(), bn=e.bn.cpu(), global_step=e.global_step.cpu(),
-                    layout=dict(id_num=self._id_num, r=e.r))
+        return dict(params=e.params.clone(), m=e.m.clone(), v=e.v.clone(), bn=e.bn.clone(), global_step=e.global_step.clone(),
+                    layout=self._layout_dict())
+
+    def state_dict(self):
+        return {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self._snapshot().items()}
 
     def load_state_dict(self, sd):
         e = self.engine
@@ -203,9 +240,126 @@ class Tacotron():
         mine = dict(id_num=self._id_num, r=e.r)
         if {k: int(lay.get(k, -1)) for k in mine} != mine or tuple(sd['params'].shape) != tuple(e.params.shape):
             raise ValueError('checkpoint layout %s (%d parameters) does not match the model %s (%d parameters)'
-                             % (lay, sd['params'].numel(), mine, e.params.numel()))
+                             % ({k: lay.get(k) for k in mine}, sd['params'].numel(), mine, e.params.numel()))
+        if lay.get('signature') is not None and lay['signature'] != e.L.signature():
+            theirs = {n: (o, tuple(sh)) for n, o, sh in lay.get('entries', [])}
+            ours = {n: (o, tuple(sh)) for n, o, sh in e.L.describe()}
+            bad = sorted(set(theirs) ^ set(ours)) + sorted(n for n in set(theirs) & set(ours) if theirs[n] != ours[n])
+            raise ValueError('checkpoint was written with a different parameter layout (first differing entries: %s)' % bad[:5])
         e.params.copy_(sd['params']); e.m.copy_(sd['m']); e.v.copy_(sd['v']); e.bn.copy_(sd['bn'])
         e.global_step.copy_(sd['global_step'])
+
+
+def checkpoint_id_num(sd):
+    """Speaker count of a checkpoint (the reference's synthesizer.py:23-25 reads the shape of 'model/inference/embedding_id'
+    from the TF checkpoint): rows of the 'embedding_id' entry of the named layout, 0 for a single-speaker model."""
+    lay = sd.get('layout', {})
+    for name, _, shape in lay.get('entries', []):
+        if name == 'embedding_id':
+            return int(shape[0])
+    return int(lay.get('id_num', 0))
+
+
+class Ticket(object):
+    """A submitted, not yet collected training step (Tacotron.submit_step)."""
+
+    def __init__(self, model, done, pinned, dims, batch, snap):
+        self.model, self.done, self.pinned, self.dims, self.batch, self.snapshot = model, done, pinned, dims, batch, snap
+        self.status = None
+
+    def state_dict(self):
+        """Host copy of the state cloned right behind this step (submit_step(snapshot=True))."""
+        if self.snapshot is None:
+            raise ValueError('this step was submitted without snapshot=True')
+        return {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.snapshot.items()}
+
+
+class _Stager(threading.Thread):
+    """numpy batches of the feeder -> device, off the training thread.  RING slots of (pinned host buffers, device buffers), both
+    grow-only; slot reuse is ordered on the device (the copy stream waits for the `done` event of the step that read the slot)
+    and on the host (the previous copy out of the pinned buffers is complete before they are overwritten)."""
+    RING = 3
+    NAMES = ('inputs', 'input_lengths', 'mel_targets', 'linear_targets', 'wavs', 'identities')
+    DTYPES = (torch.int32, torch.int32, torch.float32, torch.float32, None, torch.int32)
+
+    def __init__(self, feeder, dev, with_ids):
+        super(_Stager, self).__init__()
+        self.daemon = True
+        self.feeder, self.dev, self.with_ids = feeder, dev, with_ids
+        self.stream = torch.cuda.Stream(device=dev)
+        self.free = queue.Queue()
+        self.staged = queue.Queue()
+        self.slots = [dict(index=i, pinned={}, device={}, copied=None) for i in range(self.RING)]
+        for sl in self.slots:
+            self.free.put((sl, None))
+        self._stop_flag = False
+        self.error = None
+        self.host_copy_s = 0.0          # seconds spent copying numpy -> pinned (bench.py reports it per batch)
+        self.batches = 0
+
+    def get(self):
+        item = self.staged.get()
+        if item is None:
+            self.staged.put(None)       # stays at the end
+            if self.error is not None:
+                raise self.error
+        return item
+
+    def release(self, slot, done_event):
+        self.free.put((slot, done_event))
+
+    def stop(self):
+        self._stop_flag = True
+        self.free.put((None, None))
+
+    @staticmethod
+    def _grow(store, name, numel, dt, make):
+        flat = store.get(name)
+        if flat is None or flat.numel() < numel:
+            flat = make(max(numel, 1), dt)
+            store[name] = flat
+        return flat
+
+    def run(self):
+        import time
+        try:
+            if self.dev.index is not None:
+                torch.cuda.set_device(self.dev)
+            while not self._stop_flag:
+                slot, done = self.free.get()
+                if slot is None:
+                    break
+                batch = self.feeder.dequeue()
+                if batch is None:
+                    break
+                if slot['copied'] is not None:
+                    slot['copied'].synchronize()        # the last copy OUT of this slot's pinned buffers has finished
+                out = []
+                with torch.cuda.stream(self.stream):
+                    if done is not None:
+                        self.stream.wait_event(done)   # the step that read this slot's device buffers has finished
+                    t0 = time.perf_counter()
+                    for name, dt, arr in zip(self.NAMES, self.DTYPES, batch):
+                        if dt is None or (name == 'identities' and not self.with_ids):
+                            out.append(None)
+                            continue
+                        src = torch.as_tensor(np.ascontiguousarray(arr))
+                        pin = self._grow(slot['pinned'], name, src.numel(), dt, lambda n, d: torch.empty(n, dtype=d).pin_memory())
+                        dev = self._grow(slot['device'], name, src.numel(), dt, lambda n, d: torch.empty(n, dtype=d, device=self.dev))
+                        pv = pin[:src.numel()].view(src.shape)
+                        pv.copy_(src)                   # converts the dtype if needed; releases the GIL
+                        dv = dev[:src.numel()].view(src.shape)
+                        dv.copy_(pv, non_blocking=True)
+                        out.append(dv)
+                    self.host_copy_s += time.perf_counter() - t0
+                    self.batches += 1
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                slot['copied'] = ev
+                self.staged.put((out, ev, batch, slot))
+        except Exception as ex:                         # surfaces in the training thread at its next get()
+            self.error = ex
+        self.staged.put(None)
 
 
 def _learning_rate_decay(init_lr, global_step):

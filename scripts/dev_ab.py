@@ -21,7 +21,7 @@ def t(fn, n):
 for _ in range(5): step()
 ts = sorted(t(step, 10) for _ in range(5))
 tf = sorted(t(fwd, 10) for _ in range(3))
-print('%%-40s step %%.3f ms (min of 5x10)  median %%.3f   fwd %%.3f ms   err %%d' %% (os.environ.get('AB_NAME'), ts[0], ts[2], tf[0], int(eng.err.item())), flush=True)
+print('%%-40s step %%.3f ms (min of 5x10)  median %%.3f   fwd %%.3f ms   err %%d' %% (os.environ.get('AB_NAME'), ts[0], ts[2], tf[0], int(eng.err[0].item())), flush=True)
 ''' % ROOT
 for spec in sys.argv[1:]:
     env = dict(os.environ, AB_NAME=spec)

@@ -30,4 +30,4 @@ for _ in range(3): g.replay()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): g.replay()
 torch.cuda.synchronize()
-print('graph ms/step %.3f   err %d' % ((time.perf_counter() - t0) / 20 * 1e3, int(eng.err.item())))
+print('graph ms/step %.3f   err %d' % ((time.perf_counter() - t0) / 20 * 1e3, int(eng.err[0].item())))

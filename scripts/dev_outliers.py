@@ -38,7 +38,7 @@ for i in range(K):
 torch.cuda.synchronize()
 ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(K)])
 med = np.median(ms)
-print('median %.3f ms  mean %.3f  max %.3f  err %d  host enqueue median %.2f ms max %.2f' % (med, ms.mean(), ms.max(), int(eng.err.item()), np.median(host), max(host)))
+print('median %.3f ms  mean %.3f  max %.3f  err %d  host enqueue median %.2f ms max %.2f' % (med, ms.mean(), ms.max(), int(eng.err[0].item()), np.median(host), max(host)))
 top = np.argsort(host)[-4:][::-1]
 print('  largest host enqueue times:', ', '.join('step %d: %.1f ms' % (i, host[i]) for i in top))
 for i in np.nonzero(ms > 1.2 * med)[0]:

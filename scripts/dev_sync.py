@@ -18,4 +18,4 @@ for mode in ('back-to-back', 'sync every step', 'sync + stage events', 'back-to-
         if mode != 'back-to-back':
             torch.cuda.synchronize()
     torch.cuda.synchronize()
-    print('%-18s %.3f ms/step  err %d' % (mode, (time.time() - t0) / 20 * 1e3, int(eng.err.item())), flush=True)
+    print('%-18s %.3f ms/step  err %d' % (mode, (time.time() - t0) / 20 * 1e3, int(eng.err[0].item())), flush=True)

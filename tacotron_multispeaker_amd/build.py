@@ -21,7 +21,9 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')]
+    inc = os.path.join(os.path.dirname(HERE), 'include')
+    deps = (sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h'))]
+            + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h')])
     return any(os.path.getmtime(d) > t for d in deps)
 
 

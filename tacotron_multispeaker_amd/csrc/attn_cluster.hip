@@ -460,14 +460,11 @@ extern "C" int taco_attn_cluster_fwd_variant(int N, int Ti) {
 }
 
 int attn_cluster_fwd_launch(const AttnClu& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* ks[4] = {(const void*)attn_cluster_fwd_k<false, 2>, (const void*)attn_cluster_fwd_k<true, 2>,
-                             (const void*)attn_cluster_fwd_k<false, 5>, (const void*)attn_cluster_fwd_k<true, 5>};
-        for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TACO_EINVAL;
-        attr_set = true;
-    }
+    static DevMask attr_set[4] = {{0}, {0}, {0}, {0}};
+    const void* ks[4] = {(const void*)attn_cluster_fwd_k<false, 2>, (const void*)attn_cluster_fwd_k<true, 2>,
+                         (const void*)attn_cluster_fwd_k<false, 5>, (const void*)attn_cluster_fwd_k<true, 5>};
+    for (int i = 0; i < 4; ++i)
+        if (ensure_dyn_lds(ks[i], 160 * 1024, attr_set[i]) != TACO_OK) return TACO_EINVAL;
     // granule epochs count the steps of the whole pass, so only the pass's first chunk launch needs a zero-filled buffer
     if (p.s0 == 0 && hipMemsetAsync(p.xchg, 0, (size_t)(taco_attn_cluster_xchg_slots(p.N, p.Ti) - 16) * sizeof(u64), st) != hipSuccess)
         return TACO_EINVAL;
@@ -923,14 +920,11 @@ extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
 }
 
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* ks[4] = {(const void*)attn_cluster_bwd_k<false, 2>, (const void*)attn_cluster_bwd_k<true, 2>,
-                             (const void*)attn_cluster_bwd_k<false, 5>, (const void*)attn_cluster_bwd_k<true, 5>};
-        for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TACO_EINVAL;
-        attr_set = true;
-    }
+    static DevMask attr_set[4] = {{0}, {0}, {0}, {0}};
+    const void* ks[4] = {(const void*)attn_cluster_bwd_k<false, 2>, (const void*)attn_cluster_bwd_k<true, 2>,
+                         (const void*)attn_cluster_bwd_k<false, 5>, (const void*)attn_cluster_bwd_k<true, 5>};
+    for (int i = 0; i < 4; ++i)
+        if (ensure_dyn_lds(ks[i], 160 * 1024, attr_set[i]) != TACO_OK) return TACO_EINVAL;
     if (attn_cluster_bwd_smem(p.Ti, false) > 160 * 1024) return TACO_EINVAL;
     if (p.s1 == p.S && hipMemsetAsync(p.xchg, 0, (size_t)(taco_attn_cluster_bwd_xchg_slots(p.N, p.Ti) - 16) * sizeof(u64), st) != hipSuccess)
         return TACO_EINVAL;

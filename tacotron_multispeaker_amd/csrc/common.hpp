@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/taco_hip.h"   // prototypes are checked against the definitions
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,6 +23,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TACO_RETURN_LAST() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? TACO_OK : (int)e_; } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (kernel, device) pair: remembered per DEVICE in a bit mask next to
+// the kernel (a cache of an idempotent call, safe from any thread), never as "done once per process".
+typedef std::atomic<unsigned long long> DevMask;
+static inline int ensure_dyn_lds(const void* kernel, int bytes, DevMask& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return TACO_EINVAL;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return TACO_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return TACO_EINVAL;
+    done.fetch_or(bit, std::memory_order_release);
+    return TACO_OK;
+}
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3 };
 

@@ -415,8 +415,8 @@ static int attn_rnn_bwd_steps(const void* const* ptrs, const int* dims, hipStrea
     const float* zeros = F(TACO_AP_ZEROS);
     float* dhcarry = G(TACO_AP_DHCARRY);      // [N,256] gradient wrt h_s arriving from step s+1 (zero at s = S-1)
     float* dctxcarry = G(TACO_AP_DCTXCARRY);  // [N,256] gradient wrt ctx_s arriving from step s+1's prenet
-    hipMemsetAsync(dhcarry, 0, (size_t)N * 256 * sizeof(float), st);
-    hipMemsetAsync(dctxcarry, 0, (size_t)N * 256 * sizeof(float), st);
+    if (hipMemsetAsync(dhcarry, 0, (size_t)N * 256 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(dctxcarry, 0, (size_t)N * 256 * sizeof(float), st) != hipSuccess) return TACO_EINVAL;
     const dim3 gT(N, cdiv(Ti, 16));
     for (int s = S - 1; s >= 0; --s) {
         const bool first = s == 0;

@@ -360,27 +360,22 @@ __global__ __launch_bounds__(GT2, 2) void gru256_cluster_bwd_k(Gru256 p) {
 }
 
 static int gru256_grid(int N) { return 4 * ((N + 1) / 2); }
-// Isolation pad: unused dynamic LDS bytes per workgroup.  The kernels need 6-7 KB of LDS, so up to three GEMM workgroups (48 KB each:
-// fp32 MFMA streams that hold the SIMDs for 64 cycles per instruction) can share a CU with a GRU workgroup and stretch its steps 1.3-3x
-// whenever projection / conv / weight-gradient GEMMs are in flight.  With 150 KB of pad a GRU workgroup owns its CU, like the attention
-// workgroups do by their real LDS footprint.  Pays while every persistent workgroup of the decoder pipeline still gets a CU of its own
-// (attention 4 N + two GRUs 2 N each <= 256, i.e. N <= 32: C2 7.72 -> 7.65 ms, C4 5.91 -> 5.86, C5 12.28 -> 12.22); at N = 64 the
-// GEMMs then have nowhere to go (12.28 -> 12.35 ms), so larger batches run unpadded.  TACO_GRU256_PAD=<bytes> overrides the rule.
-static size_t gru256_lds_pad(const void* k, int N) {
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("TACO_GRU256_PAD"); forced = e ? atoi(e) : -1; }
-    const int pad = forced >= 0 ? forced : (8 * N <= 256 ? 150000 : 0);
-    static const void* done[2] = {nullptr, nullptr};
-    if (pad > 0 && done[0] != k && done[1] != k) {
-        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 155000);
-        if (!done[0]) done[0] = k; else done[1] = k;
-    }
-    return pad > 0 ? (size_t)(pad > 155000 ? 155000 : pad) : 0;
+// Isolation pad (isolate_lds_bytes, chosen by the caller): unused dynamic LDS bytes per workgroup.  The kernels need 6-7 KB of LDS, so
+// up to three GEMM workgroups (48 KB each: fp32 MFMA streams that hold the SIMDs for 64 cycles per instruction) can share a CU with a GRU
+// workgroup and stretch its steps 1.3-3x whenever projection / conv / weight-gradient GEMMs are in flight.  With 150 KB of pad a GRU
+// workgroup owns its CU, like the attention workgroups do by their register footprint.  Pays while every persistent workgroup of the
+// decoder pipeline still gets a CU of its own (attention 4 N + two GRUs 2 N each <= 256, i.e. N <= 32: C2 7.72 -> 7.65 ms, C4 5.91 -> 5.86,
+// C5 12.28 -> 12.22) and nothing else needs those CUs: the host (engine.py) passes 0 for larger batches and under data parallelism, where
+// the RCCL kernels must find room beside the GRU workgroups.
+static size_t gru256_lds_pad(const void* k, int bytes, DevMask& done) {
+    if (bytes <= 0) return 0;
+    if (ensure_dyn_lds(k, 155000, done) != TACO_OK) return 0;
+    return (size_t)(bytes > 155000 ? 155000 : bytes);
 }
 
 extern "C" int taco_gru256_seq_fwd(const float* xp, const float* whg, const float* whc, const float* res, float* r, float* u,
                                    float* c, float* rh, float* h, float* d, void* xchg, int* err, int N, int S,
-                                   int s0, int s1, hipStream_t st) {
+                                   int s0, int s1, int isolate_lds_bytes, hipStream_t st) {
     if (!xp || !whg || !whc || !r || !u || !c || !rh || !h || !xchg || !err || N <= 0 || S <= 0) return TACO_EINVAL;
     if (s0 < 0 || s1 > S || s0 >= s1) return TACO_EINVAL;
     if (d && !res) return TACO_EINVAL;
@@ -391,13 +386,14 @@ extern "C" int taco_gru256_seq_fwd(const float* xp, const float* whg, const floa
     Gru256 p{};
     p.xp = xp; p.whg = whg; p.whc = whc; p.res = res; p.r = r; p.u = u; p.c = c; p.rh = rh; p.h = h; p.d = d;
     p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1; p.xcd_local = gru_xcd_local_allowed();
-    hipLaunchKernelGGL(gru256_cluster_fwd_k, dim3(gru256_grid(N)), dim3(GT2), gru256_lds_pad((const void*)gru256_cluster_fwd_k, N), st, p);
+    static DevMask attr{0};
+    hipLaunchKernelGGL(gru256_cluster_fwd_k, dim3(gru256_grid(N)), dim3(GT2), gru256_lds_pad((const void*)gru256_cluster_fwd_k, isolate_lds_bytes, attr), st, p);
     TACO_RETURN_LAST();
 }
 
 extern "C" int taco_gru256_seq_bwd(const float* dout, const float* whg, const float* whc, const float* r, const float* u,
                                    const float* c, const float* h, float* dxp, float* carry, void* xchg, int* err, int N,
-                                   int S, int s0, int s1, hipStream_t st) {
+                                   int S, int s0, int s1, int isolate_lds_bytes, hipStream_t st) {
     if (!dout || !whg || !whc || !r || !u || !c || !h || !dxp || !carry || !xchg || !err || N <= 0 || S <= 0) return TACO_EINVAL;
     if (s0 < 0 || s1 > S || s0 >= s1) return TACO_EINVAL;
     if (gru256_grid(N) > 256) return TACO_EINVAL;
@@ -407,6 +403,7 @@ extern "C" int taco_gru256_seq_bwd(const float* dout, const float* whg, const fl
     p.dout = dout; p.whg = whg; p.whc = whc; p.r = const_cast<float*>(r); p.u = const_cast<float*>(u);
     p.c = const_cast<float*>(c); p.h = const_cast<float*>(h); p.dxp = dxp;
     p.xchg = (u64*)xchg; p.err = err; p.N = N; p.S = S; p.s0 = s0; p.s1 = s1; p.carry = carry; p.xcd_local = gru_xcd_local_allowed();
-    hipLaunchKernelGGL(gru256_cluster_bwd_k, dim3(gru256_grid(N)), dim3(GT2), gru256_lds_pad((const void*)gru256_cluster_bwd_k, N), st, p);
+    static DevMask attr{0};
+    hipLaunchKernelGGL(gru256_cluster_bwd_k, dim3(gru256_grid(N)), dim3(GT2), gru256_lds_pad((const void*)gru256_cluster_bwd_k, isolate_lds_bytes, attr), st, p);
     TACO_RETURN_LAST();
 }

@@ -240,11 +240,8 @@ extern "C" int taco_highway4_fwd(const float* x0, const float* const* W4, const 
         p.W[l] = W4[l]; p.b[l] = b4[l]; p.Z[l] = Z4[l]; p.y[l] = y4[l];
     }
     constexpr size_t smem = (HWF_ROWS * HW_LDX + 2 * HW_BK * 256) * sizeof(float);      // 49.7 KB
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)highway4_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return TACO_EINVAL;
-        attr = true;
-    }
+    static DevMask attr{0};
+    if (ensure_dyn_lds((const void*)highway4_fwd_k, (int)smem, attr) != TACO_OK) return TACO_EINVAL;
     hipLaunchKernelGGL(highway4_fwd_k, dim3(cdiv(M, HWF_ROWS)), dim3(256), smem, stream, p);
     TACO_RETURN_LAST();
 }
@@ -259,11 +256,8 @@ extern "C" int taco_highway4_bwd(const float* dy, const float* const* HT4, const
         p.HT[l] = HT4[l]; p.xin[l] = xin4[l]; p.W[l] = W4[l]; p.dZ[l] = dZ4[l];
     }
     constexpr size_t smem = (32 * HW_LDX + 32 * HWB_LDZ + 2 * HW_D * HWB_LDW) * sizeof(float);      // 70.6 KB
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)highway4_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return TACO_EINVAL;
-        attr = true;
-    }
+    static DevMask attr{0};
+    if (ensure_dyn_lds((const void*)highway4_bwd_k, (int)smem, attr) != TACO_OK) return TACO_EINVAL;
     hipLaunchKernelGGL(highway4_bwd_k, dim3(cdiv(M, 32)), dim3(256), smem, stream, p);
     TACO_RETURN_LAST();
 }

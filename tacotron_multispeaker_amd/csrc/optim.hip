@@ -78,6 +78,33 @@ __global__ void scale_k(float* __restrict__ x, long n4, float s) {
     }
 }
 
+// Everything the host reads back after a step (train.py:142-152: global_step, loss, loss_regularity; :23-36: the summary scalars)
+// packed into 16 doubles, so that ONE small device-to-host copy behind one event replaces four blocking reads:
+//  0 mel L1 sum  1 linear L1 sum (all columns)  2 linear L1 sum (priority columns)  3 loss_regularity  4 global norm (before the
+//  clip)  5 learning rate  6 clip factor  7 global_step (after the step)  8 error word  9 clusters on the agent-scope fallback
+//  10 clusters that ran the placement check  11-15 reserved (0)
+__global__ void step_status_k(const double* __restrict__ loss_sums, const double* __restrict__ reg, const float* __restrict__ info,
+                              const int* __restrict__ err, const int* __restrict__ step, double* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t >= 16) return;
+    double v = 0.0;
+    if (t < 3 && loss_sums) {           // replica r: {all columns, priority columns}; mel replicas first, linear replicas at +16
+        const int base = t == 0 ? 0 : 16, col = t == 2 ? 1 : 0;
+        for (int r = 0; r < TACO_L1_REPL; ++r) v += loss_sums[base + 2 * r + col];
+    } else if (t == 3) v = reg ? reg[0] : 0.0;
+    else if (t >= 4 && t <= 6) v = info ? (double)info[t - 4] : 0.0;
+    else if (t == 7) v = step ? (double)*step : 0.0;
+    else if (t >= 8 && t <= 10) v = err ? (double)err[t - 8] : 0.0;
+    out[t] = v;
+}
+
+extern "C" int taco_step_status(const double* loss_sums, const double* reg_sum, const float* info3, const int* err4,
+                                const int* global_step, double* out16, hipStream_t stream) {
+    if (!out16) return TACO_EINVAL;
+    hipLaunchKernelGGL(step_status_k, dim3(1), dim3(64), 0, stream, loss_sums, reg_sum, info3, err4, global_step, out16);
+    TACO_RETURN_LAST();
+}
+
 extern "C" int taco_sumsq(const float* x, long n, double* acc, hipStream_t stream) {
     if (!x || !acc || n < 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return TACO_EINVAL;
     const long n4 = n / 4;

@@ -52,6 +52,9 @@ __device__ __forceinline__ bool cluster_shares_xcd(u64* slots, int w, int cw, in
         if (!ok || (unsigned)x != mine) *flag_l = 0;
     }
     __syncthreads();
+    // placement statistics next to the error word (err[0] = hand-off timeout): err[2] counts the clusters that ran the placement
+    // check, err[1] those that keep the agent-scope form although the L2-local form was allowed (members on different XCDs)
+    if (allow && err && tid == 0 && w == 0) { atomicAdd(err + 2, 1); if (*flag_l == 0) atomicAdd(err + 1, 1); }
     return *flag_l != 0;
 }
 

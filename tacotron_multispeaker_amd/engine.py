@@ -59,8 +59,13 @@ def _claim_device(dev):
     key = str(ident)
     if key in _DEVICE_LOCKS:
         return
-    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'taco_hip_gpu_%s.lock' % key.replace('/', '_'))
-    f = open(path, 'a+')
+    # a FIXED directory, never $TMPDIR: two processes started with different TMPDIR (scripts/pmc_step.sh exports its own) must
+    # still exclude each other; world-writable so that another user's process meets the same lock
+    path = os.path.join('/tmp', 'taco_hip_gpu_%s.lock' % key.replace('/', '_'))
+    try:
+        f = os.fdopen(os.open(path, os.O_RDWR | os.O_CREAT, 0o666), 'a+')
+    except PermissionError:       # the file belongs to another user and is not writable: that user's process may hold the device
+        f = open(path, 'r')
     try:
         fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
     except OSError:
@@ -102,7 +107,10 @@ class Engine:
         self.global_step = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.dscratch = self._zbuf[L.total * 4:].view(torch.float64)                 # zeroed once per step
         self.info = torch.zeros(4, **f)
-        self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # device status words of the persistent cluster kernels (include/taco_hip.h TACO_AP_ERR): [0] hand-off timeout,
+        # [1] clusters that ran on the agent-scope granule fallback although the L2-local form was allowed, [2] clusters checked
+        self.err = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self._status_dev = torch.zeros(16, dtype=torch.float64, device=self.dev)
         self._bufs = {}
         self._flat = {}                # name -> flat storage (capacity only grows, see buf())
         self._dpos = 0
@@ -188,8 +196,35 @@ class Engine:
 
     def check_errors(self):
         """raises if a bounded spin of a persistent kernel timed out (synchronises)."""
-        if int(self.err.item()) != 0:
+        if int(self.err[0].item()) != 0:
             raise RuntimeError('persistent cluster kernel reported a hand-off timeout; results are invalid')
+
+    STATUS_FIELDS = ('mel_sum', 'lin_sum', 'pri_sum', 'loss_regularity', 'global_norm', 'learning_rate', 'clip_factor',
+                     'global_step', 'err', 'xcd_fallback_clusters', 'xcd_checked_clusters')
+
+    def status_async(self, pinned16):
+        """Everything the step loop reads back (reference train.py:142-152 and the summary scalars of :23-36) in ONE 128-byte
+        device-to-host copy: taco_step_status packs the loss sums, loss_regularity, global norm, learning rate, global_step and
+        the status words into 16 doubles, which are copied into the PINNED host tensor `pinned16` behind the returned event.
+        The host never blocks here; decode with status_decode() after event.synchronize()."""
+        lib.taco_step_status(self.loss_sums, self.reg_sum, self.info, self.err, self.global_step, self._status_dev, self.st)
+        pinned16.copy_(self._status_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def status_decode(self, pinned16, dims=None):
+        """-> dict(loss, mel_loss, linear_loss, loss_regularity, global_norm, learning_rate, global_step, err, ...) from a
+        completed status_async() slot; dims = the (N, Ti, To, S) of the step it belongs to."""
+        N, Ti, To, S = dims or self.dims
+        v = [float(x) for x in pinned16.tolist()]
+        st = dict(zip(self.STATUS_FIELDS, v))
+        mel = st['mel_sum'] / (N * To * self.nm)
+        lin = 0.5 * st['lin_sum'] / (N * To * self.nf) + 0.5 * st['pri_sum'] / (N * To * self.npri)
+        st.update(mel_loss=mel, linear_loss=lin, loss=mel + lin + st['loss_regularity'], global_step=int(st['global_step']),
+                  err=int(st['err']), xcd_fallback_clusters=int(st['xcd_fallback_clusters']),
+                  xcd_checked_clusters=int(st['xcd_checked_clusters']))
+        return st
 
     @property
     def st(self):
@@ -576,8 +611,6 @@ class Engine:
         # Chunk-pipelined decoder: attention recurrence on the current stream, GRU1 / GRU2 on two more streams; chunk c
         # of GRU1 (its hoisted projections first) starts as soon as the attention kernel has finished chunk c.
         chunks = self._chunks(N, S, Ti)
-        if len(chunks) > 1:
-            self._check_residency(N, Ti)
         cur = torch.cuda.current_stream()
         sb, sc_ = (self.stream_b, self.stream_c) if len(chunks) > 1 else (cur, cur)
         Wp, bp = self.P('concat_projection/kernel'), self.P('concat_projection/bias')
@@ -642,23 +675,50 @@ class Engine:
         self.encoder_outputs = ENC.view(N, Ti, 256)
         return MEL, LIN, self.alignments
 
+    RCCL_RESERVE_CUS = 32          # CUs the persistent kernels leave to the collective kernels under data parallelism
+
+    def _persistent_wgs(self, N):
+        """(attention, GRU(256)) workgroups of one chunk launch: 8 per two rows of an attention row block, 4 per two rows of a GRU
+        row block."""
+        return 8 * ((min(N, self.ATTN_ROWS) + 1) // 2), 4 * ((min(N, self.GRU256_ROWS) + 1) // 2)
+
+    def _gru256_pad(self, N):
+        """Isolation pad of the GRU(256) cluster kernels (csrc/gru256.hip): 150 KB of unused LDS give a workgroup its CU to itself,
+        which pays while every persistent workgroup of the pipeline has a CU of its own AND nothing else needs room there: not for
+        N > 32, and not under data parallelism, where the RCCL kernels must find LDS and registers beside the GRU workgroups (the
+        attention workgroups fill their CUs' register files, so the 4 N attention CUs are closed to everything else anyway).
+        TACO_GRU256_PAD=<bytes> overrides."""
+        forced = os.environ.get('TACO_GRU256_PAD')
+        if forced is not None:
+            return int(forced)
+        attn, gru = self._persistent_wgs(N)
+        return 150000 if (self.world == 1 and attn + 2 * gru <= 256) else 0
+
     def _check_residency(self, N, Ti):
-        """Worst case of persistent workgroups in flight at once: the chunk pipeline runs one attention launch, one GRU1 and
-        one GRU2 launch concurrently on three streams (launches of one kind serialise on their stream): 8*ceil(nb/2) +
-        2 * 4*ceil(min(N,128)/2) workgroups of 512 threads (nb = min(N, 64) attention rows per launch).  All of them spin on
-        peers, so all must be resident: a CU holds two such workgroups (launch bounds (512, 2): 256 VGPRs per lane each),
-        i.e. 512 on the chip; C2 uses 128 + 64 + 64, the largest configuration allowed here (N >= 128) 256 + 128 + 128.
-        Side-stream GEMM workgroups never spin, so they can delay a cluster workgroup's dispatch but not deadlock it."""
-        attn = 8 * ((min(N, self.ATTN_ROWS) + 1) // 2)
-        gru = 4 * ((min(N, self.GRU256_ROWS) + 1) // 2)
-        if attn > 256 or gru > 256 or attn + 2 * gru > 512:
-            raise RuntimeError('persistent cluster kernels would not be co-resident: %d + 2*%d workgroups' % (attn, gru))
+        """Co-residency of the persistent workgroups the chunk pipeline keeps in flight: one attention launch, one GRU1 and one GRU2
+        launch on three streams (launches of one kind serialise on their stream).  All of them spin on cluster peers, so a launch
+        makes progress only once ALL its workgroups are placed.  One CU holds ONE of these workgroups: 512 threads = 8 waves, 2 per
+        SIMD, at 249-256 VGPRs (attention: the register file is full, nothing else fits on that CU) or 154-170 VGPRs (GRU(256): a
+        second 8-wave workgroup would need 4 waves per SIMD; waves of up to ~160 VGPRs of OTHER kernels still fit beside it unless
+        the isolation pad closes the LDS).  Rule: attention + 2 x GRU workgroups <= 256 CUs minus, under data parallelism, the CUs
+        reserved for the collective kernels (RCCL_RESERVE_CUS; they can also share the unpadded GRU CUs).  C2: 128 + 64 + 64 = 256
+        at world 1 (every CU owned); world > 1 runs unpadded.  Batches beyond that rule are NOT pipelined (_chunks returns one
+        chunk: a single stream, one persistent launch at a time, <= 256 workgroups each by the row-block limits), because two
+        partially placed launches could hold the CUs each other needs until the bounded spins give up (err word).  Side-stream GEMM
+        workgroups never spin, so they can delay a cluster workgroup's dispatch but not deadlock it."""
+        attn, gru = self._persistent_wgs(N)
+        budget = 256 - (self.RCCL_RESERVE_CUS if (self.world > 1 and self._gru256_pad(N) > 0) else 0)
+        if attn > 256 or gru > 256:
+            raise RuntimeError('persistent cluster kernels would not be co-resident: %d / %d workgroups in one launch' % (attn, gru))
+        return attn + 2 * gru <= budget
 
     def _chunks(self, N, S, Ti, k=None):
         """Step ranges for the chunk-pipelined decoder (needs the cluster path); [(0, S)] = no pipelining."""
         k = k or self.pipe_chunks
         if k <= 1 or S < 2 * k or self.no_cluster or not lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti):
             return [(0, S)]
+        if not self._check_residency(N, Ti) and os.environ.get('TACO_PIPE_OVERSUBSCRIBE', '0') != '1':
+            return [(0, S)]          # the three launches of a pipeline stage would not all be resident: run them one at a time
         plan = os.environ.get('TACO_CHUNK_PLAN', '')
         if plan:                                       # explicit relative chunk lengths, e.g. "40,36,28,16,8" (tuning aid)
             w = [float(x) for x in plan.split(':')]
@@ -702,7 +762,8 @@ class Engine:
             xchg_b = xchg[bi * self.GRU256_XCHG:]
             self._timed('decoder GRU(256) fwd (gru256_cluster_fwd_k)', (s1 - s0) * 2.0 * (n1 - n0) * 256 * 768,
                         lambda: lib.taco_gru256_seq_fwd(v(xp, 768), whg, whc, v(res, 256), v(t[0], 256), v(t[1], 256), v(t[2], 256),
-                                                        v(t[3], 256), v(t[4], 256), v(d, 256), xchg_b, self.err, n1 - n0, S, s0, s1, self.st))
+                                                        v(t[3], 256), v(t[4], 256), v(d, 256), xchg_b, self.err, n1 - n0, S, s0, s1,
+                                                        self._gru256_pad(N), self.st))
 
     def gru256_bwd(self, dout, whg, whc, r, u, c, h, dxp, carry, xchg, N, S, s0, s1):
         for bi, n0 in enumerate(range(0, N, self.GRU256_ROWS)):
@@ -711,7 +772,8 @@ class Engine:
             xchg_b = xchg[bi * self.GRU256_XCHG:]
             self._timed('decoder GRU(256) bwd (gru256_cluster_bwd_k)', (s1 - s0) * 2.0 * (n1 - n0) * 256 * 768,
                         lambda: lib.taco_gru256_seq_bwd(v(dout, 256), whg, whc, v(r, 256), v(u, 256), v(c, 256), v(h, 256), v(dxp, 768),
-                                                        carry.view(N, 256)[n0:n1], xchg_b, self.err, n1 - n0, S, s0, s1, self.st))
+                                                        carry.view(N, 256)[n0:n1], xchg_b, self.err, n1 - n0, S, s0, s1,
+                                                        self._gru256_pad(N), self.st))
 
     def dense_rows(self, x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, ldy):
         lib.taco_dense_rows_fwd(x, scope_w, bias, y, N, S, s0, s1, cin, cout, ldx, cout, ldy, 0, 0, self.st)
@@ -920,7 +982,13 @@ class Engine:
                                                                     nm, 1024, 8, 8, 1024, 128, nm, 1, self.st))
                     e = torch.cuda.Event(); e.record(sd)
                     piece_done.append(e)
-            # weight / bias gradient of the output projection: deferred; flushed after the last GRU2 chunk has waited for every piece
+            # weight / bias gradient of the output projection read the WHOLE dOUT, which stream_d is still accumulating into: whatever
+            # stream ends up running them (the side streams at any release point, or this stream when the weight gradients are not
+            # deferred at all: TACO_OVERLAP_WGRAD=0) first waits for the last piece
+            if self._side_active:
+                self._deferred.append(lambda: [ss.wait_event(piece_done[-1]) for ss in self.side_streams])
+            else:
+                cur.wait_event(piece_done[-1])
             self.gemm_dw(D2, dOUT.view(Ms, nm * r), self.G('output_projection/kernel'), Ms, 256, nm * r)
             self.colsum(dOUT.view(Ms, nm * r), self.G('output_projection/bias'), Ms, nm * r)
         else:

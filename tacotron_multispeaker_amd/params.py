@@ -104,6 +104,20 @@ class ParamLayout:
             self._add('%s/bigru/%s_whg' % (scope, d), (128, 256))
             self._add('%s/bigru/%s_whc' % (scope, d), (128, 128))
 
+    # ---- self-description (checkpoints) --------------------------------------------------------------------
+    TF_SCOPE = 'model/inference'      # reference train.py:101 opens 'model', tacotron.py:35 'inference'; synthesizer.py:25 reads
+                                      # 'model/inference/embedding_id' from a checkpoint to recover the speaker count
+
+    def describe(self):
+        """[[name, offset, shape], ...] of the trainable entries followed by the moving statistics ('bn:' prefix): the named
+        layout a checkpoint of the flat buffers stores, so that a file is self-describing and a changed layout is refused."""
+        return ([[e.name, int(e.offset), [int(d) for d in e.shape]] for e in self.entries.values()] +
+                [['bn:' + e.name, int(e.offset), [int(d) for d in e.shape]] for e in self.bn_entries.values()])
+
+    def signature(self):
+        import hashlib
+        return hashlib.sha256(repr(self.describe()).encode()).hexdigest()
+
     # ---- views -----------------------------------------------------------------------------------
     def view(self, flat, name):
         e = self.entries[name]

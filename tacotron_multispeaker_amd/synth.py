@@ -30,3 +30,56 @@ def batch_to_device(b, dev):
     import torch
     order = ('inputs', 'input_lengths', 'mel_targets', 'linear_targets', 'identities')
     return [torch.as_tensor(b[k]).to(dev) if b[k] is not None else None for k in order]
+
+
+class SyntheticFeeder(object):
+    """Stand-in for datasets.datafeeder_npy.DataFeeder with the same consumer interface (`.inputs` ... `.identities` handles
+    for Tacotron.initialize, dequeue(), a bounded queue of 8 batches filled by a background thread) that cycles through a pool
+    of pre-built synthetic batches instead of reading .npy files: bench.py's train-loop legs measure the step loop of train.py
+    (feeder handles -> stager thread -> pinned buffers -> device -> step -> one status read-back) without a dataset on disk.
+    What it leaves out is the reference feeder's own cost of producing a batch (np.load, pad, stack: reference
+    datasets/datafeeder_npy.py:96-171), which is CPU work of the reference's design and not part of the step."""
+
+    def __init__(self, batches, n_batches=None):
+        import queue
+        import threading
+        from datasets.datafeeder_npy import FeedTensor
+        names = ('inputs', 'input_lengths', 'mel_targets', 'linear_targets', 'wavs', 'identities')
+        (self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.wavs,
+         self.identities) = [FeedTensor(self, i, n) for i, n in enumerate(names)]
+        self._pool = [(b['inputs'], b['input_lengths'], b['mel_targets'], b['linear_targets'], None, b['identities']) for b in batches]
+        self._queue = queue.Queue(maxsize=8)
+        self._n = n_batches
+        self._stopped = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def start_in_session(self, session=None):
+        self._thread.start()
+
+    def stop(self):
+        self._stopped.set()
+
+    def _run(self):
+        import queue
+        i = 0
+        while not self._stopped.is_set() and (self._n is None or i < self._n):
+            try:
+                self._queue.put(self._pool[i % len(self._pool)], timeout=0.2)
+                i += 1
+            except queue.Full:
+                continue
+        while not self._stopped.is_set():
+            try:
+                self._queue.put(None, timeout=0.2)
+                return
+            except queue.Full:
+                continue
+
+    def dequeue(self, timeout=1.0):
+        import queue
+        while True:
+            try:
+                return self._queue.get(timeout=timeout)
+            except queue.Empty:
+                if self._stopped.is_set():
+                    return None

@@ -99,6 +99,36 @@ def test_training_step_matches_oracle(cfg):
     _oracle_step_compare(P, b, r, idn)
 
 
+@pytest.mark.parametrize('env,cfg', [({'TACO_XCD_LOCAL': '0'}, (3, 33, 16, 1, 7)),       # odd batch, 4 pipeline chunks of 4 steps
+                                     ({'TACO_XCD_LOCAL': '0'}, (5, 40, 120, 5, 0)),      # odd batch, S = 24
+                                     ({'TACO_OVERLAP_WGRAD': '0'}, (4, 48, 120, 5, 0)),   # weight gradients on the main stream
+                                     ({'TACO_FLUSH_AT': '0'}, (4, 48, 120, 5, 0))])       # post-net dW released after the FIRST chunk
+def test_training_step_on_the_alternative_paths_matches_oracle(env, cfg, monkeypatch):
+    """Paths a default run does not take, each a full training step against the float64 oracle:
+    * TACO_XCD_LOCAL=0: every persistent cluster keeps the agent-scope granule form (`global_store sc1`) -- the
+      placement-independent hand-off a cluster falls back to when its members are not on one XCD (csrc/xcd_granule.hpp); the
+      placement counters stay 0 because no cluster runs the check, while a default engine counts every cluster launch;
+    * TACO_OVERLAP_WGRAD=0 / TACO_FLUSH_AT=0: the output-projection weight gradient reads the whole dOUT that the post-net bank's
+      input-gradient pieces accumulate into on another stream -- it must wait for the last piece wherever it is emitted."""
+    from oracle import tacotron_np as onp
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N, Ti, To, r, idn = cfg
+    P = onp.init_params(seed=27, r=r, id_num=idn)
+    rng = np.random.RandomState(8)
+    for k in P:
+        if k.endswith(('/bias', '/beta')):
+            P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+    b = onp.synth_batch(N, Ti, To, r, seed=35, id_num=idn)
+    o, _ = _oracle_step_compare(P, b, r, idn)
+    words = [int(x) for x in o['eng'].err.cpu().tolist()]
+    assert words[0] == 0
+    if 'TACO_XCD_LOCAL' in env:
+        assert words[1] == 0 and words[2] == 0
+    else:
+        assert words[2] > 0 and 0 <= words[1] <= words[2]
+
+
 @pytest.mark.parametrize('cfg', [(66, 14, 20, 5, 0), (2, 300, 30, 5, 0), (130, 10, 15, 5, 3)])
 def test_shapes_beyond_one_cluster_launch_match_oracle(cfg):
     """Limits of the persistent cluster kernels: one attention launch holds <= 64 batch rows (8 workgroups per 2 rows on
@@ -214,6 +244,11 @@ def test_full_size_multispeaker_configs(name, N, Ti, To, r, idn):
     eng.check_errors()
     second = eng.loss_values()[0]
     assert np.isfinite(second) and second < first and int(eng.global_step.item()) == 2
+    del eng
+    # and the whole step -- every gradient tensor, the global norm, the post-step parameters -- against the FLOAT64 oracle at the
+    # full shape: C5 is the longest BPTT chain of BASELINE.json (S = 400 decoder steps, register-weight attention variants, four
+    # pipeline chunks of 100 steps), where fp32 error accumulates most
+    _oracle_step_compare(P, b, r, idn)
 
 
 def test_full_size_c2_training_step_matches_float64_oracle():
@@ -685,6 +720,71 @@ def test_checkpoint_resume_reproduces_the_next_step():
     importlib.reload(H)
 
 
+def test_pipelined_submit_collect_and_snapshot():
+    """The loop train.py runs (reference train.py:139-152, pipelined one step deep): submit_step() enqueues a step and its one
+    128-byte status copy, collect() waits for that copy only.  With step k+1 submitted before step k is collected the reported
+    (global_step, loss, loss_regularity, learning rate, gradient norm) equal those of the synchronous run_step() loop, and a
+    snapshot requested with step 2 holds exactly the state after step 2 although steps 3 and 4 were enqueued before it was read
+    (what train.py writes as model.ckpt-<step>; checkpoint_id_num recovers the speaker count like synthesizer.py:23-25)."""
+    import importlib
+    import hparams as H
+    importlib.reload(H)
+    from models import create_model
+    from models.tacotron import GlobalStep, checkpoint_id_num
+    from oracle import tacotron_np as onp
+    H.hparams.parse('outputs_per_step=5,initial_learning_rate=0.001,decay_learning_rate=false')
+    bs = [onp.synth_batch(3, 14 + 2 * i, 30 + 5 * i, 5, seed=80 + i, id_num=4) for i in range(4)]      # a new shape every step
+
+    def make():
+        m = create_model('tacotron', H.hparams)
+        m.initialize(bs[0]['inputs'], bs[0]['input_lengths'], bs[0]['mel_targets'], bs[0]['linear_targets'],
+                     identities=bs[0]['identities'], id_num=4, seed=3)
+        m.add_loss(); m.add_optimizer(GlobalStep())
+        return m
+
+    def feed(m, b):
+        m._set_batch(b['inputs'], b['input_lengths'], b['mel_targets'], b['linear_targets'], b['identities'])
+
+    a = make()
+    ref, state2 = [], None
+    for i, b in enumerate(bs):
+        feed(a, b)
+        out = a.run_step()
+        ref.append((out[0], out[1], a.mel_loss, a.linear_loss, a.learning_rate, a.max_gradient_norm))
+        if i == 1:
+            state2 = a.state_dict()
+    p = make()
+    tickets, got = [], []
+    for i, b in enumerate(bs):
+        feed(p, b)
+        tickets.append(p.submit_step(snapshot=(i == 1)))
+        if len(tickets) == 2:                       # one step stays in flight behind the one that is collected
+            t = tickets.pop(0)
+            out = p.collect(t)
+            got.append((out[0], out[1], p.mel_loss, p.linear_loss, p.learning_rate, p.max_gradient_norm, t))
+    out = p.collect(tickets[0])
+    got.append((out[0], out[1], p.mel_loss, p.linear_loss, p.learning_rate, p.max_gradient_norm, tickets[0]))
+    for r_, g_ in zip(ref, got):
+        assert g_[0] == r_[0]
+        for x, y in zip(r_[1:], g_[1:6]):
+            assert abs(x - y) < 1e-5 * abs(x)       # atomics reorder fp32 sums from launch to launch
+    snap = got[1][6].state_dict()
+    assert int(snap['global_step'].item()) == 2 and checkpoint_id_num(snap) == 4
+    assert snap['layout']['tf_scope'] == 'model/inference' and any(n == 'embedding_id' for n, _, _ in snap['layout']['entries'])
+    for k in ('params', 'm', 'v', 'bn'):
+        assert float((snap[k] - state2[k]).abs().max()) < 1e-5, k
+    assert float((snap['params'] - p.engine.params.cpu()).abs().max()) > 1e-4       # two more steps have been applied since
+    with pytest.raises(ValueError):
+        got[0][6].state_dict()                      # submitted without snapshot=True
+    st = got[-1][6].status
+    assert st['err'] == 0 and st['xcd_checked_clusters'] > 0 and 0 <= st['xcd_fallback_clusters'] <= st['xcd_checked_clusters']
+    # a layout with the same parameter count but other entry offsets / names is refused by its signature
+    bad = dict(snap); bad['layout'] = dict(snap['layout'], signature='0' * 64, entries=[['embedding', 4, [7352, 256]]])
+    with pytest.raises(ValueError, match='different parameter layout'):
+        p.load_state_dict(bad)
+    importlib.reload(H)
+
+
 def _toy_dataset(tmp_path, n=12):
     import json
     rng = np.random.RandomState(0)
@@ -736,18 +836,18 @@ def test_train_py_restore_step_and_spike_rollback(tmp_path, monkeypatch):
     assert steps[0] == 6 and steps[-1] == 8
 
     import models.tacotron as MT
-    orig = MT.Tacotron.run_step
+    orig = MT.Tacotron.collect
     fired = []
 
     def spiky_at(k):
-        def run_step(self):
-            out = orig(self)
-            if out is not None and out[0] == k and not fired:
+        def collect(self, ticket):        # train.py's loop: submit_step() ... collect(); the spike is seen one step late
+            out = orig(self, ticket)
+            if out[0] == k and not fired:
                 fired.append(k)
                 return (out[0], out[1] * 100.0, out[2], out[3])
             return out
-        return run_step
-    monkeypatch.setattr(MT.Tacotron, 'run_step', spiky_at(18))
+        return collect
+    monkeypatch.setattr(MT.Tacotron, 'collect', spiky_at(18))
     log3 = _run_train(tmp_path, monkeypatch, ['--restore_step', '5', '--max_steps', '20', '--checkpoint_interval', '5'])
     new = log3[len(log2):]
     assert fired == [18] and 'recover to the previous checkpoint' in new
@@ -756,7 +856,7 @@ def test_train_py_restore_step_and_spike_rollback(tmp_path, monkeypatch):
     assert 'Exiting due to exception' not in new
 
     del fired[:]
-    monkeypatch.setattr(MT.Tacotron, 'run_step', spiky_at(3))
+    monkeypatch.setattr(MT.Tacotron, 'collect', spiky_at(3))
     monkeypatch.setattr('sys.argv', [])
     import importlib
     import sys
@@ -810,6 +910,18 @@ def test_data_parallel_exchange_plumbing_single_rank_rccl():
             assert np.abs(pn[k] - v.detach().numpy()).max() < 1e-5, k
     finally:
         dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_through_the_engine(request):
+    """SURVEY.md 8(e) with two REAL ranks on the one GPU of the box (scripts/dp_two_ranks.py, started by tests/conftest.py before
+    this process touched the device): both ranks run Engine.train_step with world = 2 on rank-specific batches; backward launches the
+    four gradient buckets in order [0, 1, 2, 3] behind the producer events, the step-1 update equals the float64 oracle's update on
+    the averaged gradient, replicas stay bit-identical for 3 steps of changing shapes, no hand-off times out.  The collective itself
+    is gloo (RCCL does not take two ranks on one device): RCCL over xGMI stays unmeasured until an 8-GPU record exists."""
+    rc, out = getattr(request.config, '_dp_two_ranks', (-1, 'the run was not started (conftest.pytest_collection_finish)'))
+    assert rc == 0, out[-4000:]
+    assert out.count('PASS') == 2 and 'RESULT: OK' in out
+    assert out.count('bucket order [0, 1, 2, 3]') == 6
 
 
 def test_changing_batch_shapes_reuse_the_workspace():

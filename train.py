@@ -67,10 +67,24 @@ def train(log_dir, args):
     model.add_optimizer(global_step)
     model.engine.world = world
 
+    # a tiny host-side (gloo) group carries the per-step agreement of the replicas: it must not sit on the GPU streams, where it
+    # would force a device synchronisation per step
+    ctl = dist.new_group(backend='gloo') if world > 1 else None
+
+    def agree(*flags):
+        """MAX over ranks of a few small integers (1 rank: identity).  Every rank takes the same branch afterwards."""
+        if world == 1:
+            return list(flags)
+        t = torch.tensor(flags, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        return [int(x) for x in t]
+
     step = 0
     steps_run = 0                    # --max_steps also bounds the number of iterations, so a run that keeps rolling back ends
     time_window = ValueWindow(250)
     loss_window = ValueWindow(1000)
+    saved = []                       # checkpoints on disk, oldest first (max_to_keep=5, keep_checkpoint_every_n_hours=8: reference :117)
+    kept_forever_at = time.time()
     try:
         if args.restore_step:
             restore_path = '%s-%d' % (checkpoint_path, args.restore_step)
@@ -79,47 +93,103 @@ def train(log_dir, args):
         else:
             log('Starting new training run')
         feeder.start_in_session(None)
-        while not coord.should_stop():
-            start_time = time.time()
-            out = model.run_step()
-            if out is None:
+        # The loop of reference train.py:139-152, pipelined one step deep: step k+1 is submitted BEFORE the host waits for the
+        # scalars of step k (one 128-byte copy behind an event), so the GPU never idles while the host enqueues.  The host knows
+        # the number every submitted step will get (global_step increments once per step), so the checkpoint of step k is cloned
+        # on the device right behind step k although it is written to disk only after step k's loss has been looked at; the
+        # rollback target int((step-10)/interval)*interval (reference :154-160) does not depend on the one-step-late decision.
+        next_step = global_step.value() + 1
+        inflight = []
+        last_t = time.time()
+        submitting = True
+
+        def may_submit():
+            if not submitting or coord.should_stop() or len(inflight) >= 2:
+                return False
+            return not (args.max_steps and (next_step > args.max_steps or steps_run + len(inflight) >= args.max_steps))
+
+        while True:
+            while may_submit():
+                # replicas agree BEFORE a step is enqueued (it contains the gradient all-reduce: a rank that enqueued it while
+                # another rank has no batch would wait for that rank forever)
+                failure = 0
+                try:
+                    have = model.next_batch_ready()
+                except Exception as e:          # feeder / staging error on this rank
+                    log('Exiting due to exception: %s' % e)
+                    traceback.print_exc()
+                    coord.request_stop(e)
+                    have, failure = False, 1
+                failure, missing = agree(failure, 0 if have else 1)
+                if failure or missing:
+                    submitting = False
+                    break
+                t = model.submit_step(snapshot=(next_step % args.checkpoint_interval == 0))
+                t.step_number = next_step
+                next_step += 1
+                inflight.append(t)
+            if not inflight:
                 break
-            step, loss, _, loss_regularity = out
-            time_window.append(time.time() - start_time)
+            t = inflight.pop(0)
+            err_flag = 0
+            try:
+                step, loss, _, loss_regularity = model.collect(t)
+            except RuntimeError as e:           # hand-off timeout on this rank: the optimizer skipped the step on the device
+                log('Exiting due to exception: %s' % e)
+                coord.request_stop(e)
+                err_flag, step, loss, loss_regularity = 1, t.step_number, float('nan'), 0.0
+            now = time.time()
+            time_window.append(now - last_t)
+            last_t = now
             loss_window.append(loss)
             log('Step %-7d [%.03f avg_sec/step,  loss=%.05f,  avg_loss=%.05f,  lossw=%.05f]' % (
                 step, time_window.average, loss, loss_window.average, loss_regularity))
             # if the gradient seems to explode, then restore to the previous step (reference :154-160).  Under data
-            # parallelism the replicas must take the same branch: the decision is the OR over ranks (each rank only sees the
-            # loss of its own shard), and a rank reads a checkpoint only after rank 0 has finished writing it.
-            spike = bool(loss > 2 * loss_window.average or math.isnan(loss))
-            if world > 1:
-                flag = torch.tensor([1 if spike else 0], device='cuda:%d' % local, dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                spike = bool(flag.item())
+            # parallelism the replicas must take the same branch: the decision is the MAX over ranks of [error, spike] (each
+            # rank only sees the loss of its own shard), and a rank reads a checkpoint only after rank 0 has finished writing it.
+            spike = 1 if (loss > 2 * loss_window.average or math.isnan(loss)) else 0
+            err_flag, spike = agree(err_flag, spike)
+            if err_flag:
+                break
+            if step % args.summary_interval == 0:
+                # the scalars of reference add_stats (:23-36), from values the step already holds (TF histograms: out of scope)
+                log('Summary at step %d: loss_mel=%.05f  loss_linear=%.05f  learning_rate=%.3e  max_gradient_norm=%.05f' % (
+                    step, model.mel_loss, model.linear_loss, model.learning_rate, model.max_gradient_norm))
             if spike:
                 log('recover to the previous checkpoint')
                 restore_step = int((step - 10) / args.checkpoint_interval) * args.checkpoint_interval
                 restore_path = '%s-%d' % (checkpoint_path, restore_step)
+                # steps submitted behind the spike are discarded with it (the restore is ordered behind them on the stream);
                 # a missing checkpoint raises (like saver.restore at reference :159) instead of training on with NaN weights
+                inflight = []
                 model.load_state_dict(torch.load(restore_path, weights_only=True))
+                next_step = restore_step + 1
+                saved = [p for p in saved if int(p.rsplit('-', 1)[1]) <= restore_step]
                 steps_run += 1
-                if args.max_steps and steps_run >= args.max_steps:
-                    coord.request_stop()
                 continue
             if step % args.checkpoint_interval == 0:
                 if rank == 0:
-                    log('Saving checkpoint to: %s-%d' % (checkpoint_path, step))
-                    torch.save(model.state_dict(), '%s-%d' % (checkpoint_path, step))
+                    path = '%s-%d' % (checkpoint_path, step)
+                    log('Saving checkpoint to: %s' % path)
+                    torch.save(t.state_dict(), path)        # the state cloned right behind step `step` (later steps are in flight)
+                    saved.append(path)
+                    while len(saved) > 5:                   # tf.train.Saver(max_to_keep=5, keep_checkpoint_every_n_hours=8)
+                        old = saved.pop(0)
+                        if os.path.getmtime(old) - kept_forever_at >= 8 * 3600:
+                            kept_forever_at = os.path.getmtime(old)
+                        elif os.path.exists(old):
+                            os.remove(old)
                 if world > 1:
-                    dist.barrier()          # the file is complete before any rank may roll back to it
+                    dist.barrier(group=ctl)     # the file is complete before any rank may roll back to it
+            t.snapshot = None
             steps_run += 1
-            if args.max_steps and (step >= args.max_steps or steps_run >= args.max_steps):
-                coord.request_stop()
     except Exception as e:
         log('Exiting due to exception: %s' % e)
         traceback.print_exc()
         coord.request_stop(e)
+    finally:
+        coord.request_stop()
+        model.stop()
 
 
 def main():
