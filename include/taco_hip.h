@@ -208,6 +208,9 @@ int taco_step_inc(int* global_step, const int* err, hipStream_t stream);
 int taco_step_status(const double* loss_sums, const double* reg_sum, const float* info3, const int* err4, const int* global_step,
                      double* out16, hipStream_t stream);
 int taco_scale(float* x, long n, float s, hipStream_t stream);
+/* a one-wave kernel that idles for `us` microseconds (<= 100 ms): the host's probe of which streams share a hardware queue
+ * (tacotron_multispeaker_amd/engine.py Engine._pick_streams); not part of a training step */
+int taco_spin_us(int us, hipStream_t stream);
 /* zero-fill (one memset node): bytes and p must be multiples of 16 */
 int taco_zero(void* p, size_t bytes, hipStream_t stream);
 

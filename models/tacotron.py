@@ -100,7 +100,7 @@ class Tacotron():
     def _next_staged(self):
         """(device tensors, ready event, numpy batch, ring slot) of the next batch; None once the feeder has stopped."""
         if self._stager is None:
-            self._stager = _Stager(self._feeder, self.engine.dev, bool(self._id_num))
+            self._stager = _Stager(self._feeder, self.engine.dev, bool(self._id_num), self.engine.copy_stream())
             self._stager.start()
         return self._stager.get()
 
@@ -282,17 +282,18 @@ class _Stager(threading.Thread):
     NAMES = ('inputs', 'input_lengths', 'mel_targets', 'linear_targets', 'wavs', 'identities')
     DTYPES = (torch.int32, torch.int32, torch.float32, torch.float32, None, torch.int32)
 
-    def __init__(self, feeder, dev, with_ids):
+    def __init__(self, feeder, dev, with_ids, stream=None):
         super(_Stager, self).__init__()
         self.daemon = True
         self.feeder, self.dev, self.with_ids = feeder, dev, with_ids
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.free = queue.Queue()
         self.staged = queue.Queue()
         self.slots = [dict(index=i, pinned={}, device={}, copied=None) for i in range(self.RING)]
         for sl in self.slots:
             self.free.put((sl, None))
         self._stop_flag = False
+        self._pool = None
         self.error = None
         self.host_copy_s = 0.0          # seconds spent copying numpy -> pinned (bench.py reports it per batch)
         self.batches = 0
@@ -311,6 +312,25 @@ class _Stager(threading.Thread):
     def stop(self):
         self._stop_flag = True
         self.free.put((None, None))
+
+    COPY_THREADS = 4
+    COPY_SPLIT_BYTES = 8 << 20
+
+    def _host_copy(self, dst, src):
+        """numpy -> pinned host memory (dtype converted if needed).  Large arrays (the 84 MB linear targets) are cut into row blocks
+        copied by a small private thread pool: np.copyto releases the GIL, a single thread moves ~10 GB/s, i.e. 9 ms per C2 batch --
+        longer than the training step.  Deliberately NOT torch's intra-op pool: that one is sized by the host's CPU count (256 on
+        the GPU boxes, of which a 1-GPU job owns 16), and its spinning workers starve the training thread's kernel launches."""
+        if src.nbytes < self.COPY_SPLIT_BYTES or src.shape[0] < 2:
+            np.copyto(dst, src, casting='unsafe')
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(self.COPY_THREADS)
+        n = src.shape[0]
+        cuts = [n * i // self.COPY_THREADS for i in range(self.COPY_THREADS + 1)]
+        list(self._pool.map(lambda k: np.copyto(dst[cuts[k]:cuts[k + 1]], src[cuts[k]:cuts[k + 1]], casting='unsafe'),
+                            range(self.COPY_THREADS)))
 
     @staticmethod
     def _grow(store, name, numel, dt, make):
@@ -343,12 +363,12 @@ class _Stager(threading.Thread):
                         if dt is None or (name == 'identities' and not self.with_ids):
                             out.append(None)
                             continue
-                        src = torch.as_tensor(np.ascontiguousarray(arr))
-                        pin = self._grow(slot['pinned'], name, src.numel(), dt, lambda n, d: torch.empty(n, dtype=d).pin_memory())
-                        dev = self._grow(slot['device'], name, src.numel(), dt, lambda n, d: torch.empty(n, dtype=d, device=self.dev))
-                        pv = pin[:src.numel()].view(src.shape)
-                        pv.copy_(src)                   # converts the dtype if needed; releases the GIL
-                        dv = dev[:src.numel()].view(src.shape)
+                        src = np.ascontiguousarray(arr)
+                        pin = self._grow(slot['pinned'], name, src.size, dt, lambda n, d: torch.empty(n, dtype=d).pin_memory())
+                        dev = self._grow(slot['device'], name, src.size, dt, lambda n, d: torch.empty(n, dtype=d, device=self.dev))
+                        pv = pin[:src.size].view(src.shape)
+                        self._host_copy(pv.numpy(), src)
+                        dv = dev[:src.size].view(src.shape)
                         dv.copy_(pv, non_blocking=True)
                         out.append(dv)
                     self.host_copy_s += time.perf_counter() - t0

@@ -61,7 +61,7 @@ def run(mode):
     for _ in range(K):
         e.train_step(*args)
     torch.cuda.synchronize()
-    print('         back-to-back %.3f ms/step' % ((time.perf_counter() - t0) / K * 1e3), flush=True)
+    print('         back-to-back %.3f ms/step   status words %s' % ((time.perf_counter() - t0) / K * 1e3, e.err.cpu().tolist()), flush=True)
     del m
 
 

@@ -149,3 +149,16 @@ extern "C" int taco_scale(float* x, long n, float s, hipStream_t stream) {
     hipLaunchKernelGGL(scale_k, dim3((int)g), dim3(256), 0, stream, x, n / 4, s);
     TACO_RETURN_LAST();
 }
+
+// One wave that does nothing for `us` microseconds (constant 100 MHz wall clock): used by the host ONCE per engine to find out which of
+// its streams share a hardware queue -- two such kernels on streams that share one run back to back, on different queues side by side.
+__global__ void spin_us_k(long ticks) {
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int taco_spin_us(int us, hipStream_t stream) {
+    if (us < 0 || us > 100000) return TACO_EINVAL;
+    hipLaunchKernelGGL(spin_us_k, dim3(1), dim3(64), 0, stream, (long)us * 100);
+    TACO_RETURN_LAST();
+}

@@ -114,18 +114,27 @@ class Engine:
         self._bufs = {}
         self._flat = {}                # name -> flat storage (capacity only grows, see buf())
         self._dpos = 0
-        # Stream priorities: the weight-gradient GEMMs of the side stream(s) are bulk work with slack; queued at the same priority
-        # as the critical path their big grids hold the dispatcher while short critical kernels (highway / BN chains, the next
-        # recurrence chunk) wait behind them.  TACO_PRIO = "<critical>:<side>" (HIP: lower number = higher priority).
+        # Streams.  A step needs FOUR concurrent command streams: the caller's (main), two more for the stages of the decoder chunk
+        # pipeline (stream_b, stream_c) and one auxiliary stream that carries, at different times of the step, the post-net conv-bank
+        # pieces behind the decoder pipeline and the deferred weight-gradient GEMMs (side_streams[0] == stream_d).  Four is also what
+        # the hardware offers without penalty: ROCm multiplexes all HIP streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware
+        # queues (one per compute pipe), and two streams that share a queue run strictly one after the other.  Measured at C2 (round
+        # 3, profiles/r03_stream_queues.md): every stream on its own queue 7.43 ms; the auxiliary stream sharing the main stream's
+        # queue 8.57 ms; five or more hardware queues (GPU_MAX_HW_QUEUES >= 5: two active queues per pipe) 10.1 ms.  Which pool
+        # stream lands on which queue is the runtime's choice, so the engine does not assume it: _pick_streams() measures it once.
         pr = [int(x) for x in os.environ.get('TACO_PRIO', '0:0').split(':')]
-        self.side_streams = [torch.cuda.Stream(device=self.dev, priority=pr[1]) for _ in range(max(1, int(os.environ.get('TACO_SIDE_STREAMS', '1'))))]
+        self.main_stream = torch.cuda.Stream(device=self.dev, priority=pr[0]) if pr[0] != 0 else None
+        picked = self._pick_streams(3, pr)
+        self.stream_b, self.stream_c = picked[0], picked[1]     # decoder pipeline stages (GRU1 / GRU2 or attention)
+        self.side_streams = [picked[2]] + [torch.cuda.Stream(device=self.dev, priority=pr[1])
+                                           for _ in range(max(1, int(os.environ.get('TACO_SIDE_STREAMS', '1'))) - 1)]
+        if os.environ.get('TACO_MERGE_AUX', '1') != '0':
+            self.stream_d = self.side_streams[0]               # post-net conv bank pieces behind the decoder pipeline
+        else:
+            self.stream_d = torch.cuda.Stream(device=self.dev, priority=pr[0])
         self._side_rr = 0
         self._side_active = False
         self._deferred = []
-        self.stream_b = torch.cuda.Stream(device=self.dev, priority=pr[0])      # decoder pipeline stages (GRU1 / GRU2 or attention)
-        self.stream_c = torch.cuda.Stream(device=self.dev, priority=pr[0])
-        self.stream_d = torch.cuda.Stream(device=self.dev, priority=pr[0])      # post-net conv bank pieces behind the decoder pipeline
-        self.main_stream = torch.cuda.Stream(device=self.dev, priority=pr[0]) if pr[0] != 0 else None
         self.pipe_chunks = int(os.environ.get('TACO_CHUNKS', '4'))
         self.pipe_chunks_bwd = int(os.environ.get('TACO_CHUNKS_BWD', str(self.pipe_chunks)))
         self.last_chunk_frac = float(os.environ.get('TACO_LAST_CHUNK', '0.7'))     # last chunk length / (S / chunks)
@@ -137,10 +146,78 @@ class Engine:
         self.post_pipe = os.environ.get('TACO_POST_PIPE', '1') != '0'          # post-net conv bank chunk by chunk behind the decoder
         self.no_cluster = os.environ.get('TACO_NO_CLUSTER', '0') == '1'     # force the per-step attention kernels (tests)
         self.world = 1                 # data-parallel replicas (set by train.py / bench.py after init_process_group)
-        self.comm_stream = torch.cuda.Stream(device=self.dev)    # bucket all-reduces are ordered behind this stream
+        # bucket all-reduces are ordered behind this stream: a FIFTH stream would share a hardware queue with one of the four above,
+        # and the only one whose work it may sit behind without stalling the critical path is the auxiliary stream (the gradient
+        # buckets are produced there anyway)
+        self.comm_stream = self._queue_mate(self.side_streams[0]) if os.environ.get('TACO_COMM_ON_AUX_QUEUE', '1') != '0' \
+            else torch.cuda.Stream(device=self.dev)
         self._exchange = None
         self.exposed_events = None     # bench: list of (event, event) pairs around the wait for the gradient exchange
         self.load_named(named_params if named_params is not None else init_named(L, seed))
+
+    # ---- stream selection ----------------------------------------------------------------------------------
+    PROBE_US = 300
+
+    def _serialised(self, a, b):
+        """True when kernels on streams a and b run one after the other, i.e. the two streams share a hardware queue: two idle
+        kernels of PROBE_US microseconds take 2 x PROBE_US instead of 1 x (host clock around a device synchronisation)."""
+        import time
+        best = 1e9
+        for _ in range(2):
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            lib.taco_spin_us(self.PROBE_US, a.cuda_stream)
+            lib.taco_spin_us(self.PROBE_US, b.cuda_stream)
+            a.synchronize(); b.synchronize()
+            best = min(best, (time.perf_counter() - t0) * 1e6)
+        return best > 1.6 * self.PROBE_US
+
+    def _pick_streams(self, n, pr):
+        """n streams from torch's pool that are pairwise on different hardware queues and not on the current (main) stream's queue.
+        Falls back to the first pool streams when the runtime offers fewer queues (GPU_MAX_HW_QUEUES < 4) or TACO_STREAM_PROBE=0."""
+        main = self.main_stream if self.main_stream is not None else torch.cuda.current_stream(self.dev)
+        cands = [torch.cuda.Stream(device=self.dev, priority=pr[0]) for _ in range(int(os.environ.get('TACO_STREAM_CANDIDATES', '12')))]
+        self._stream_pool, self._stream_classes = cands, None
+        if os.environ.get('TACO_STREAM_PROBE', '1') == '0':
+            return cands[:n]
+        with torch.cuda.device(self.dev):
+            lib.taco_spin_us(1, main.cuda_stream)          # module load / first-launch cost out of the measurement
+            torch.cuda.synchronize(self.dev)
+            chosen = []
+            for c in cands:
+                if all(not self._serialised(c, o) for o in [main] + chosen):
+                    chosen.append(c)
+                    if len(chosen) == n:
+                        break
+        self.stream_probe = dict(found=len(chosen), wanted=n)
+        for c in cands:                                     # not enough distinct queues: fill up in pool order
+            if len(chosen) < n and c not in chosen:
+                chosen.append(c)
+        return chosen
+
+    def _queue_mate(self, stream, exclude=()):
+        """A pool stream that shares `stream`'s hardware queue (or `stream` itself when the probe finds none)."""
+        if os.environ.get('TACO_STREAM_PROBE', '1') == '0':
+            return torch.cuda.Stream(device=self.dev)
+        with torch.cuda.device(self.dev):
+            for c in self._stream_pool:
+                if c is not stream and c not in (self.stream_b, self.stream_c) and all(c is not x for x in exclude) \
+                        and self._serialised(c, stream):
+                    return c
+        return stream
+
+    def copy_stream(self):
+        """Stream for the host-to-device staging copies of the NEXT batch (models/tacotron.py _Stager).  A copy occupies the
+        hardware queue of its stream until it has finished (~2-4 ms for a 91 MB C2 batch), so it must not share a queue with the
+        main stream or the decoder pipeline stages: TACO_COPY_STREAM = aux (default: a stream on the auxiliary stream's queue, whose
+        work has slack), high (a high-priority stream: the runtime keeps separate queues per priority), pool (next pool stream)."""
+        mode = os.environ.get('TACO_COPY_STREAM', 'aux')
+        if mode == 'high':
+            return torch.cuda.Stream(device=self.dev, priority=-1)
+        if mode == 'pool':
+            return torch.cuda.Stream(device=self.dev)
+        mate = self._queue_mate(self.side_streams[0], exclude=(self.comm_stream,))
+        return mate if mate is not self.side_streams[0] else torch.cuda.Stream(device=self.dev)
 
     # ---- parameters ---------------------------------------------------------------------------------------
     def load_named(self, named):
@@ -986,7 +1063,8 @@ class Engine:
             # stream ends up running them (the side streams at any release point, or this stream when the weight gradients are not
             # deferred at all: TACO_OVERLAP_WGRAD=0) first waits for the last piece
             if self._side_active:
-                self._deferred.append(lambda: [ss.wait_event(piece_done[-1]) for ss in self.side_streams])
+                # (a stream never waits for its own event: inside a HIP-graph capture that self-edge crashes hipStreamEndCapture)
+                self._deferred.append(lambda: [ss.wait_event(piece_done[-1]) for ss in self.side_streams if ss is not sd])
             else:
                 cur.wait_event(piece_done[-1])
             self.gemm_dw(D2, dOUT.view(Ms, nm * r), self.G('output_projection/kernel'), Ms, 256, nm * r)

@@ -767,7 +767,7 @@ def test_pipelined_submit_collect_and_snapshot():
     for r_, g_ in zip(ref, got):
         assert g_[0] == r_[0]
         for x, y in zip(r_[1:], g_[1:6]):
-            assert abs(x - y) < 1e-5 * abs(x)       # atomics reorder fp32 sums from launch to launch
+            assert abs(x - y) < 2e-4 * abs(x)       # atomics reorder fp32 sums from launch to launch; 4 steps at lr 1e-3 amplify it
     snap = got[1][6].state_dict()
     assert int(snap['global_step'].item()) == 2 and checkpoint_id_num(snap) == 4
     assert snap['layout']['tf_scope'] == 'model/inference' and any(n == 'embedding_id' for n, _, _ in snap['layout']['entries'])

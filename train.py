@@ -42,6 +42,7 @@ def train(log_dir, args):
     hparams.num_GPU = max(len(GPUs_id), world)
     local = int(os.environ.get('LOCAL_RANK', str(GPUs_id[0])))
     torch.cuda.set_device(local)
+    torch.set_num_threads(4)         # no torch CPU compute on the path: keep the intra-op pool (sized by the HOST's CPU count) out of the way
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
