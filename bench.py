@@ -306,7 +306,7 @@ def main():
                 s.copy_(t)
 
     def fwd_bwd():
-        eng.forward(static[0], static[1], static[2], static[4])
+        eng.forward(static[0], static[1], static[2], static[4], linear_targets=static[3])     # as Engine.train_step does
         eng.loss(static[3])
         eng.backward()
 

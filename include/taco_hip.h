@@ -119,6 +119,11 @@ int taco_highway4_fwd(const float* x0, const float* const* W4, const float* cons
                       int M, hipStream_t stream);
 int taco_highway4_bwd(const float* dy, const float* const* HT4, const float* const* xin4, const float* const* W4,
                       float* const* dZ4, float* dx, int M, hipStream_t stream);
+/* the same over the FRAMES [f0, f1) of every length-T sequence of the [N,T,*] tensors (rows n*T + f; tiles never cross a sequence) */
+int taco_highway4_fwd_rows(const float* x0, const float* const* W4, const float* const* b4, float* const* Z4, float* const* y4,
+                           int N, int T, int f0, int f1, hipStream_t stream);
+int taco_highway4_bwd_rows(const float* dy, const float* const* HT4, const float* const* xin4, const float* const* W4,
+                           float* const* dZ4, float* dx, int N, int T, int f0, int f1, hipStream_t stream);
 int taco_relu_bwd(const float* y, const float* dy, float* dpre, long n, hipStream_t stream);
 int taco_add(const float* a, const float* b, float* y, long n, int accumulate, hipStream_t stream);
 
@@ -128,6 +133,10 @@ int taco_add(const float* a, const float* b, float* y, long n, int accumulate, h
 #define TACO_L1_REPL 8
 int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2, long rows,
                  int C, int npri, float w_all, float w_pri, hipStream_t stream);
+/* the same over the FRAMES [f0, f1) of every length-T sequence of [N,T,*] tensors (rows n*T + f): lets the loss of the frames a
+ * chunk of the post-net biGRU completes run beside the next chunk; the sums ADD into sums2 (zeroed once per step by the caller) */
+int taco_l1_loss_rows(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2, int N, int T,
+                      int f0, int f1, int C, int npri, float w_all, float w_pri, hipStream_t stream);
 
 /* ---- optional alignment regularisers (models/tacotron.py:140-171; hparams overwrought / oneorder_dynamic /
  * variance_between_row / alignment_entropy, all 0.0 by default).  align [N,S,Ti] (the layout the attention kernels save;
@@ -141,12 +150,17 @@ int taco_align_regularity(const float* align, float* dalign, double* loss_sum, i
  * xp [N,T,ldxp]: hoisted x.W_x + b per direction d at columns [d*384, d*384+384) ordered r|u|c;
  * wg [128,256], wc [128,128]: recurrent halves of the GRUCell gates/candidate kernels;
  * out [N,T,ldo] direction d at columns [d*128, ..); ruc [ndir,N,T,384] saved gates for BPTT. */
+/* [s0, s1): step range of this launch in processing order (forward pass: step s touches frame s of direction 0 and frame T-1-s of
+ * direction 1; BPTT: the mirror image).  The recurrence may be cut into chunk launches issued in order, so that work on the frames a
+ * chunk completes (both directions done) can run beside the next chunk; the recurrent state passes through state [ndir,N,128]
+ * (required unless the launch covers [0, T)).  isolate_lds_bytes: see taco_gru256_seq_fwd. */
 int taco_gru128_seq_fwd(const float* xp, int ldxp, const float* wg_fw, const float* wc_fw, const float* wg_bw,
                         const float* wc_bw, const int* lengths, float* out, int ldo, float* ruc, int N, int T, int ndir,
-                        hipStream_t stream);
+                        int s0, int s1, float* state, int isolate_lds_bytes, hipStream_t stream);
 int taco_gru128_seq_bwd(const float* dout, int lddo, const float* wg_fw, const float* wc_fw, const float* wg_bw,
                         const float* wc_bw, const int* lengths, const float* out, int ldo, const float* ruc, float* dxp,
-                        int ldxp, float* hp, float* rh, int N, int T, int ndir, hipStream_t stream);
+                        int ldxp, float* hp, float* rh, int N, int T, int ndir, int s0, int s1, float* state,
+                        int isolate_lds_bytes, hipStream_t stream);
 
 /* ---- attention decoder (models/tacotron.py:66-97, rnn_wrappers.py, helpers.py:41-82) ---------------------------- */
 int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int num_mels, hipStream_t stream);

@@ -9,3 +9,9 @@ extern "C" {
 int taco_dev_xchg_bench(void* xchg, int* err, float* sink, int nclus, int cw, int len, int iters, int same_xcd, int sleep,
                         int threads, int mode, hipStream_t stream);
 }
+extern "C" {
+// synthetic background load for interference studies (scripts/dev_interfere.py; engine.py TACO_DEV_LOAD, developer knob):
+// mode 0 = HBM/L2 streaming reads over [p, p + bytes) `reps` times, mode 1 = fp32 MFMA chain without memory traffic for `reps`
+// iterations; wgs workgroups of 256 threads with lds_bytes of dynamic LDS each (occupancy control)
+int taco_dev_load(const float* p, long bytes, int reps, int mode, int wgs, int lds_bytes, float* sink, hipStream_t stream);
+}

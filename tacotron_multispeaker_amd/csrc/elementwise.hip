@@ -377,16 +377,18 @@ __global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, 
 // sums[2*rep + 0] += sum|d| over all columns, sums[2*rep + 1] += sum|d| over columns < npri  (rep = workgroup % TACO_L1_REPL);
 // grad[row, c] = sign(out - tgt) * (w_all + (c < npri ? w_pri : 0)); padded columns [C, ldg) get 0.
 // =====================================================================================================
+// rb_len > 0: logical row r is frame rb_off + r % rb_len of sequence r / rb_len (physical row (r / rb_len) * rb_stride + ...)
 __global__ __launch_bounds__(256) void l1_loss_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt,
                                                 float* __restrict__ grad, int ldg, double* __restrict__ sums, long rows, int C,
-                                                int npri, float w_all, float w_pri) {
+                                                int npri, float w_all, float w_pri, int rb_len, int rb_stride, int rb_off) {
     // flat (row, column) index over the padded gradient width: consecutive lanes touch consecutive floats (rows of 1025 floats
     // are not 16-byte aligned, so 4-byte lanes are the coalesced access) and all lanes stay busy for narrow rows (80 mels);
     // four independent elements per lane and iteration keep enough loads in flight
     float s_all = 0.f, s_pri = 0.f;
     const unsigned total = (unsigned)(rows * ldg), stride = gridDim.x * 256u;
     auto one = [&](unsigned e) {
-        const unsigned r = e / (unsigned)ldg, c = e - r * (unsigned)ldg;
+        const unsigned rl = e / (unsigned)ldg, c = e - rl * (unsigned)ldg;
+        const unsigned r = rb_len ? (rl / (unsigned)rb_len) * (unsigned)rb_stride + (unsigned)rb_off + rl % (unsigned)rb_len : rl;
         float gv = 0.f;
         if ((int)c < C) {
             const float d = out[(long)r * ldo + c] - tgt[(long)r * ldt + c];
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void l1_loss_k(const float* __restrict__ out, 
             if ((int)c < npri) { s_pri += a; w += w_pri; }
             gv = d > 0.f ? w : (d < 0.f ? -w : 0.f);
         }
-        if (grad) grad[e] = gv;
+        if (grad) grad[(long)r * ldg + c] = gv;
     };
     unsigned e = blockIdx.x * 256u + threadIdx.x;
     for (; e + 3u * stride < total && e + 3u * stride >= e; e += 4u * stride) { one(e); one(e + stride); one(e + 2u * stride); one(e + 3u * stride); }
@@ -701,6 +703,16 @@ extern "C" int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt
                             long rows, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
     if (!out || !tgt || !sums2 || ldg < C || (ldg & 3) || rows * ldg >= (1L << 31)) return TACO_EINVAL;
     const long blocks = (rows * ldg + 1023) / 1024;
-    hipLaunchKernelGGL(l1_loss_k, dim3((int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri);
+    hipLaunchKernelGGL(l1_loss_k, dim3((int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri, 0, 0, 0);
+    TACO_RETURN_LAST();
+}
+
+extern "C" int taco_l1_loss_rows(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2, int N,
+                                 int T, int f0, int f1, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
+    if (!out || !tgt || !sums2 || ldg < C || (ldg & 3) || N <= 0 || T <= 0 || f0 < 0 || f1 > T || f0 >= f1) return TACO_EINVAL;
+    if ((long)N * T * ldg >= (1L << 31)) return TACO_EINVAL;
+    const long rows = (long)N * (f1 - f0);
+    const long blocks = (rows * ldg + 1023) / 1024;
+    hipLaunchKernelGGL(l1_loss_k, dim3((int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri, f1 - f0, T, f0);
     TACO_RETURN_LAST();
 }

@@ -42,6 +42,11 @@ struct GruSeq {
     float* dxp;           // [N,T,ldxp]   gradient wrt xp (same layout as xp)
     float* hp;            // [ndir,N,T,128] h_{prev} per step  (for dW_h gates  = hp^T . dxp[:, 0:256])
     float* rh;            // [ndir,N,T,128] r*h_{prev}         (for dW_h cand   = rh^T . dxp[:, 256:384])
+    // step range of this launch (processing order: step s touches frame s of the forward direction and frame T-1-s of the backward
+    // direction in the forward pass, the mirror image in BPTT): the recurrence may be cut into chunk launches issued in order, so
+    // that work on the frames a chunk completes can start while the next chunk runs; the state travels through `state`
+    int s0, s1;
+    float* state;         // [ndir,N,128]: h after step s1-1 (forward) / dh after step s1-1 (BPTT); read when s0 > 0, written when s1 < T
 };
 
 // NTH threads per workgroup: 512 (2 waves per SIMD: K of a gate column split over 2 lanes, of a candidate column over 4; default)
@@ -71,7 +76,10 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
         for (int k = 0; k < KC / 2; ++k) wc[k] = (f2){Wc[(kq * KC + 2 * k) * H + ccol], Wc[(kq * KC + 2 * k + 1) * H + ccol]};
     }
     const int len = p.lengths ? min(max(p.lengths[row], 0), p.T) : p.T;
+    float* hst = p.state ? p.state + ((long)dir * p.N + row) * H : nullptr;
     for (int i = tid; i < LLEN(H); i += NTH) { h_l[i] = 0.0f; rh_l[i] = 0.0f; }
+    __syncthreads();
+    if (p.s0 > 0 && tid < H) h_l[LIDX(tid)] = hst[tid];          // state left by the previous chunk launch
     __syncthreads();
 
     const int xoff = dir * 3 * H;
@@ -82,14 +90,14 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
     auto tstep = [&](int s) { return dir == 0 ? s : p.T - 1 - s; };
     float xg = 0.f, xc = 0.f;
     {
-        const int t = tstep(0);
+        const int t = tstep(p.s0);
         if (kh == 0) xg = xrow[(long)t * p.ldxp + gcol];
         if (kq == 0) xc = xrow[(long)t * p.ldxp + 2 * H + ccol];
     }
-    for (int s = 0; s < p.T; ++s) {
+    for (int s = p.s0; s < p.s1; ++s) {
         const int t = tstep(s);
         const float ag = xg, ac = xc;
-        if (s + 1 < p.T) {                              // prefetch the next step's input projection
+        if (s + 1 < p.s1) {                             // prefetch the next step's input projection
             const int tn = tstep(s + 1);
             if (kh == 0) xg = xrow[(long)tn * p.ldxp + gcol];
             if (kq == 0) xc = xrow[(long)tn * p.ldxp + 2 * H + ccol];
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
         }
         lds_barrier();
     }
+    if (p.s1 < p.T && tid < H) hst[tid] = h_l[LIDX(tid)];        // for the next chunk launch
 }
 
 // BPTT twin.  Processing order is the reverse of the forward order of that direction.  Hidden index k is owned by
@@ -175,8 +184,9 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
     float* dxrow = p.dxp + (long)row * p.T * p.ldxp + xoff;
     float* hprow = p.hp + dn * p.T * H;
     float* rhrow = p.rh + dn * p.T * H;
-    float dh = 0.0f;
     const bool owner = jq == 0;
+    float* dst = p.state ? p.state + dn * H : nullptr;
+    float dh = (p.s0 > 0 && owner) ? dst[k] : 0.0f;               // dh left by the previous chunk launch
     // saved activations / incoming gradient of a step do not depend on the recurrence: fetched ONE STEP AHEAD into
     // registers so that their HBM/L2 latency is off the dependent chain
     float pf_r = 0.f, pf_u = 0.f, pf_c = 0.f, pf_h = 0.f, pf_d = 0.f;
@@ -191,14 +201,14 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
             pf_d = dorow[(long)t * p.lddo + k];
         }
     };
-    prefetch(0);
+    prefetch(p.s0);
 
-    for (int s = 0; s < p.T; ++s) {
+    for (int s = p.s0; s < p.s1; ++s) {
         const int t = dir == 0 ? p.T - 1 - s : s;          // reverse of the forward order
         const bool valid = t < len;
         const float r = pf_r, u = pf_u, c = pf_c, hprev = pf_h;
         const float dhT = (owner && valid) ? dh + pf_d : 0.f;
-        if (s + 1 < p.T) prefetch(s + 1);
+        if (s + 1 < p.s1) prefetch(s + 1);
         const float du = dhT * (hprev - c);
         float dh_new = valid ? dhT * u : dh;
         const float dcp = dhT * (1.0f - u) * (1.0f - c * c);
@@ -242,35 +252,52 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
         e = group_sum<JS>(e);
         dh = dh_new + e;
     }
+    if (p.s1 < p.T && owner) dst[k] = dh;
 }
 
 // TACO_GRU128_THREADS = 256 | 512 (default 512; measured: 256 threads = one wave per SIMD is 27 % SLOWER per step, see gru128_seq_fwd_k)
 static int gru128_threads() { const char* e = getenv("TACO_GRU128_THREADS"); return (e && atoi(e) == 256) ? 256 : 512; }
 
+// isolation pad: see csrc/gru256.hip (unused dynamic LDS: with ~150 KB a workgroup has its CU to itself)
+static size_t gru128_pad(const void* k, int bytes, DevMask& done) {
+    if (bytes <= 0) return 0;
+    if (ensure_dyn_lds(k, 158000, done) != TACO_OK) return 0;
+    return (size_t)(bytes > 150000 ? 150000 : bytes);
+}
+
 extern "C" int taco_gru128_seq_fwd(const float* xp, int ldxp, const float* wg_fw, const float* wc_fw, const float* wg_bw,
                                    const float* wc_bw, const int* lengths, float* out, int ldo, float* ruc, int N, int T,
-                                   int ndir, hipStream_t stream) {
+                                   int ndir, int s0, int s1, float* state, int isolate_lds_bytes, hipStream_t stream) {
     if (!xp || !wg_fw || !wc_fw || !out || !ruc || N <= 0 || T <= 0 || ndir < 1 || ndir > 2) return TACO_EINVAL;
     if (ndir == 2 && (!wg_bw || !wc_bw)) return TACO_EINVAL;
+    if (s0 < 0 || s1 > T || s0 >= s1 || ((s0 > 0 || s1 < T) && !state)) return TACO_EINVAL;
     GruSeq p{};
     p.xp = xp; p.ldxp = ldxp; p.wg[0] = wg_fw; p.wc[0] = wc_fw; p.wg[1] = wg_bw; p.wc[1] = wc_bw;
-    p.lengths = lengths; p.out = out; p.ldo = ldo; p.ruc = ruc; p.N = N; p.T = T;
-    if (gru128_threads() == 256) hipLaunchKernelGGL(gru128_seq_fwd_k<256>, dim3(N, ndir), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(gru128_seq_fwd_k<512>, dim3(N, ndir), dim3(512), 0, stream, p);
+    p.lengths = lengths; p.out = out; p.ldo = ldo; p.ruc = ruc; p.N = N; p.T = T; p.s0 = s0; p.s1 = s1; p.state = state;
+    static DevMask a256{0}, a512{0};
+    if (gru128_threads() == 256)
+        hipLaunchKernelGGL(gru128_seq_fwd_k<256>, dim3(N, ndir), dim3(256), gru128_pad((const void*)gru128_seq_fwd_k<256>, isolate_lds_bytes, a256), stream, p);
+    else
+        hipLaunchKernelGGL(gru128_seq_fwd_k<512>, dim3(N, ndir), dim3(512), gru128_pad((const void*)gru128_seq_fwd_k<512>, isolate_lds_bytes, a512), stream, p);
     TACO_RETURN_LAST();
 }
 
 extern "C" int taco_gru128_seq_bwd(const float* dout, int lddo, const float* wg_fw, const float* wc_fw, const float* wg_bw,
                                    const float* wc_bw, const int* lengths, const float* out, int ldo, const float* ruc,
-                                   float* dxp, int ldxp, float* hp, float* rh, int N, int T, int ndir, hipStream_t stream) {
+                                   float* dxp, int ldxp, float* hp, float* rh, int N, int T, int ndir, int s0, int s1, float* state,
+                                   int isolate_lds_bytes, hipStream_t stream) {
     if (!dout || !wg_fw || !wc_fw || !out || !ruc || !dxp || !hp || !rh || N <= 0 || T <= 0 || ndir < 1 || ndir > 2) return TACO_EINVAL;
     if (ndir == 2 && (!wg_bw || !wc_bw)) return TACO_EINVAL;
     if (ldxp & 3) return TACO_EINVAL;
+    if (s0 < 0 || s1 > T || s0 >= s1 || ((s0 > 0 || s1 < T) && !state)) return TACO_EINVAL;
     GruSeq p{};
     p.ldxp = ldxp; p.wg[0] = wg_fw; p.wc[0] = wc_fw; p.wg[1] = wg_bw; p.wc[1] = wc_bw;
     p.lengths = lengths; p.out = const_cast<float*>(out); p.ldo = ldo; p.ruc = const_cast<float*>(ruc); p.N = N; p.T = T;
-    p.dout = dout; p.lddo = lddo; p.dxp = dxp; p.hp = hp; p.rh = rh;
-    if (gru128_threads() == 256) hipLaunchKernelGGL(gru128_seq_bwd_k<256>, dim3(N, ndir), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(gru128_seq_bwd_k<512>, dim3(N, ndir), dim3(512), 0, stream, p);
+    p.dout = dout; p.lddo = lddo; p.dxp = dxp; p.hp = hp; p.rh = rh; p.s0 = s0; p.s1 = s1; p.state = state;
+    static DevMask a256{0}, a512{0};
+    if (gru128_threads() == 256)
+        hipLaunchKernelGGL(gru128_seq_bwd_k<256>, dim3(N, ndir), dim3(256), gru128_pad((const void*)gru128_seq_bwd_k<256>, isolate_lds_bytes, a256), stream, p);
+    else
+        hipLaunchKernelGGL(gru128_seq_bwd_k<512>, dim3(N, ndir), dim3(512), gru128_pad((const void*)gru128_seq_bwd_k<512>, isolate_lds_bytes, a512), stream, p);
     TACO_RETURN_LAST();
 }

@@ -32,7 +32,21 @@ struct Hw4 {
     float* Z[4];                 // [M,256] out: [relu(H) | sigmoid(T)]
     float* y[4];                 // [M,128] out: layer outputs
     int M;
+    // frame band (taco_highway4_*_rows): the tiles cover frames [rb_off, rb_off + rb_len) of every length-rb_stride sequence;
+    // rb_len = 0: the M rows as they lie
+    int rb_len, rb_stride, rb_off;
 };
+// first physical row and number of valid rows of the 32-row tile b
+__device__ __forceinline__ void hw_tile(int b, int M, int rb_len, int rb_stride, int rb_off, long& m0, int& valid) {
+    if (rb_len) {
+        const int tpb = (rb_len + 31) / 32, n = b / tpb, ft = b - n * tpb;
+        m0 = (long)n * rb_stride + rb_off + 32 * ft;
+        valid = min(32, rb_len - 32 * ft);
+    } else {
+        m0 = (long)b * 32;
+        valid = (int)min(32L, (long)M - m0);
+    }
+}
 #define HWF_ROWS 32
 
 __global__ __launch_bounds__(256, 3) void highway4_fwd_k(Hw4 p) {
@@ -41,12 +55,13 @@ __global__ __launch_bounds__(256, 3) void highway4_fwd_k(Hw4 p) {
     float (*ws)[HW_BK * 256] = reinterpret_cast<float (*)[HW_BK * 256]>(hw_smem + HWF_ROWS * HW_LDX);   // weight ring: [2][k][256 columns]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const long m0 = (long)blockIdx.x * HWF_ROWS;
+    long m0; int valid;
+    hw_tile(blockIdx.x, p.M, p.rb_len, p.rb_stride, p.rb_off, m0, valid);
     // ---- stage the input tile
     for (int v = tid; v < HWF_ROWS * 32; v += 256) {
         const int r = v >> 5, c4 = v & 31;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + r < p.M) a = *reinterpret_cast<const float4*>(p.x0 + (m0 + r) * HW_D + c4 * 4);
+        if (r < valid) a = *reinterpret_cast<const float4*>(p.x0 + (m0 + r) * HW_D + c4 * 4);
         *reinterpret_cast<float4*>(&xs[r * HW_LDX + c4 * 4]) = a;
     }
     // weight chunk c of layer l: rows k = 16 c .. +16 of W_l, all 256 columns = 16 KB = 4 float4 per thread
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256, 3) void highway4_fwd_k(Hw4 p) {
             const float xv = xs[row * HW_LDX + colH];
             const float o = hv * tv + xv * (1.f - tv);
             xs[row * HW_LDX + colH] = o;
-            if (m0 + row < p.M) {
+            if (row < valid) {
                 Zl[(m0 + row) * 256 + colH] = hv;
                 Zl[(m0 + row) * 256 + colT] = tv;
                 yl[(m0 + row) * HW_D + colH] = o;
@@ -123,6 +138,7 @@ struct Hw4B {
     float* dZ[4];                // [M,256] out: gradient wrt the pre-activations [H | T] (dW / bias gradient operand)
     float* dx;                   // [M,128] out: gradient wrt the input of layer 1
     int M;
+    int rb_len, rb_stride, rb_off;   // frame band, see Hw4
 };
 #define HWB_LDZ (256 + 4)
 #define HWB_BK 16                // K-chunk (Z columns) of the backward weight ring: 70.6 KB of LDS = two workgroups per CU
@@ -136,11 +152,12 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
     float (*ws)[HW_D * HWB_LDW] = reinterpret_cast<float (*)[HW_D * HWB_LDW]>(zs + 32 * HWB_LDZ);   // weight ring: [2][input unit n][16 Z columns]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const long m0 = (long)blockIdx.x * 32;
+    long m0; int valid;
+    hw_tile(blockIdx.x, p.M, p.rb_len, p.rb_stride, p.rb_off, m0, valid);
     for (int v = tid; v < 32 * 32; v += 256) {
         const int r = v >> 5, c4 = v & 31;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + r < p.M) a = *reinterpret_cast<const float4*>(p.dy + (m0 + r) * HW_D + c4 * 4);
+        if (r < valid) a = *reinterpret_cast<const float4*>(p.dy + (m0 + r) * HW_D + c4 * 4);
         *reinterpret_cast<float4*>(&gs[r * HW_LDX + c4 * 4]) = a;
     }
     // weight chunk c of layer l: W_l[n][16 c .. +16] for all 128 rows n = 512 float4: thread covers rows (tid >> 2) + 64 v, v < 2
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
         _Pragma("unroll") for (int v = 0; v < 4; ++v) { \
             const long m_ = m0 + (tid >> 5) + 8 * v; const int c_ = (tid & 31) * 4; \
             ph[v] = pt[v] = px[v] = make_float4(0.f, 0.f, 0.f, 0.f); \
-            if (m_ < p.M) { ph[v] = *reinterpret_cast<const float4*>(H_ + m_ * 256 + c_); \
+            if ((tid >> 5) + 8 * v < valid) { ph[v] = *reinterpret_cast<const float4*>(H_ + m_ * 256 + c_); \
                             pt[v] = *reinterpret_cast<const float4*>(H_ + m_ * 256 + 128 + c_); \
                             px[v] = *reinterpret_cast<const float4*>(X_ + m_ * HW_D + c_); } } } while (0)
     pfetch(3);
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
             dt.x = g.x * (hv.x - xv.x) * tv.x * (1.f - tv.x); dt.y = g.y * (hv.y - xv.y) * tv.y * (1.f - tv.y);
             dt.z = g.z * (hv.z - xv.z) * tv.z * (1.f - tv.z); dt.w = g.w * (hv.w - xv.w) * tv.w * (1.f - tv.w);
             dd.x = g.x * (1.f - tv.x); dd.y = g.y * (1.f - tv.y); dd.z = g.z * (1.f - tv.z); dd.w = g.w * (1.f - tv.w);
-            if (m < p.M) {
+            if (r < valid) {
                 *reinterpret_cast<float4*>(dZl + m * 256 + c) = dh;
                 *reinterpret_cast<float4*>(dZl + m * 256 + 128 + c) = dt;
             }
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float o = gs[row * HW_LDX + col] + acc[r];
                 gs[row * HW_LDX + col] = o;
-                if (l == 0 && m0 + row < p.M) p.dx[(m0 + row) * HW_D + col] = o;
+                if (l == 0 && row < valid) p.dx[(m0 + row) * HW_D + col] = o;
             }
         }
         __syncthreads();
@@ -230,11 +247,10 @@ __global__ __launch_bounds__(256, 2) void highway4_bwd_k(Hw4B p) {
 #undef pfetch
 }
 
-extern "C" int taco_highway4_fwd(const float* x0, const float* const* W4, const float* const* b4, float* const* Z4, float* const* y4,
-                                 int M, hipStream_t stream) {
-    if (!x0 || !W4 || !b4 || !Z4 || !y4 || M <= 0) return TACO_EINVAL;
+static int highway4_fwd_launch(const float* x0, const float* const* W4, const float* const* b4, float* const* Z4, float* const* y4,
+                               int M, int rb_len, int rb_stride, int rb_off, int tiles, hipStream_t stream) {
     Hw4 p{};
-    p.x0 = x0; p.M = M;
+    p.x0 = x0; p.M = M; p.rb_len = rb_len; p.rb_stride = rb_stride; p.rb_off = rb_off;
     for (int l = 0; l < 4; ++l) {
         if (!W4[l] || !b4[l] || !Z4[l] || !y4[l]) return TACO_EINVAL;
         p.W[l] = W4[l]; p.b[l] = b4[l]; p.Z[l] = Z4[l]; p.y[l] = y4[l];
@@ -242,15 +258,14 @@ extern "C" int taco_highway4_fwd(const float* x0, const float* const* W4, const 
     constexpr size_t smem = (HWF_ROWS * HW_LDX + 2 * HW_BK * 256) * sizeof(float);      // 49.7 KB
     static DevMask attr{0};
     if (ensure_dyn_lds((const void*)highway4_fwd_k, (int)smem, attr) != TACO_OK) return TACO_EINVAL;
-    hipLaunchKernelGGL(highway4_fwd_k, dim3(cdiv(M, HWF_ROWS)), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(highway4_fwd_k, dim3(tiles), dim3(256), smem, stream, p);
     TACO_RETURN_LAST();
 }
 
-extern "C" int taco_highway4_bwd(const float* dy, const float* const* HT4, const float* const* xin4, const float* const* W4,
-                                 float* const* dZ4, float* dx, int M, hipStream_t stream) {
-    if (!dy || !HT4 || !xin4 || !W4 || !dZ4 || !dx || M <= 0) return TACO_EINVAL;
+static int highway4_bwd_launch(const float* dy, const float* const* HT4, const float* const* xin4, const float* const* W4,
+                               float* const* dZ4, float* dx, int M, int rb_len, int rb_stride, int rb_off, int tiles, hipStream_t stream) {
     Hw4B p{};
-    p.dy = dy; p.dx = dx; p.M = M;
+    p.dy = dy; p.dx = dx; p.M = M; p.rb_len = rb_len; p.rb_stride = rb_stride; p.rb_off = rb_off;
     for (int l = 0; l < 4; ++l) {
         if (!HT4[l] || !xin4[l] || !W4[l] || !dZ4[l]) return TACO_EINVAL;
         p.HT[l] = HT4[l]; p.xin[l] = xin4[l]; p.W[l] = W4[l]; p.dZ[l] = dZ4[l];
@@ -258,6 +273,31 @@ extern "C" int taco_highway4_bwd(const float* dy, const float* const* HT4, const
     constexpr size_t smem = (32 * HW_LDX + 32 * HWB_LDZ + 2 * HW_D * HWB_LDW) * sizeof(float);      // 70.6 KB
     static DevMask attr{0};
     if (ensure_dyn_lds((const void*)highway4_bwd_k, (int)smem, attr) != TACO_OK) return TACO_EINVAL;
-    hipLaunchKernelGGL(highway4_bwd_k, dim3(cdiv(M, 32)), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(highway4_bwd_k, dim3(tiles), dim3(256), smem, stream, p);
     TACO_RETURN_LAST();
+}
+
+extern "C" int taco_highway4_fwd(const float* x0, const float* const* W4, const float* const* b4, float* const* Z4, float* const* y4,
+                                 int M, hipStream_t stream) {
+    if (!x0 || !W4 || !b4 || !Z4 || !y4 || M <= 0) return TACO_EINVAL;
+    return highway4_fwd_launch(x0, W4, b4, Z4, y4, M, 0, 0, 0, cdiv(M, HWF_ROWS), stream);
+}
+
+extern "C" int taco_highway4_bwd(const float* dy, const float* const* HT4, const float* const* xin4, const float* const* W4,
+                                 float* const* dZ4, float* dx, int M, hipStream_t stream) {
+    if (!dy || !HT4 || !xin4 || !W4 || !dZ4 || !dx || M <= 0) return TACO_EINVAL;
+    return highway4_bwd_launch(dy, HT4, xin4, W4, dZ4, dx, M, 0, 0, 0, cdiv(M, 32), stream);
+}
+
+// the same over the frames [f0, f1) of every length-T sequence of [N,T,*] tensors (rows n*T + f)
+extern "C" int taco_highway4_fwd_rows(const float* x0, const float* const* W4, const float* const* b4, float* const* Z4,
+                                      float* const* y4, int N, int T, int f0, int f1, hipStream_t stream) {
+    if (!x0 || !W4 || !b4 || !Z4 || !y4 || N <= 0 || T <= 0 || f0 < 0 || f1 > T || f0 >= f1) return TACO_EINVAL;
+    return highway4_fwd_launch(x0, W4, b4, Z4, y4, N * T, f1 - f0, T, f0, N * cdiv(f1 - f0, 32), stream);
+}
+
+extern "C" int taco_highway4_bwd_rows(const float* dy, const float* const* HT4, const float* const* xin4, const float* const* W4,
+                                      float* const* dZ4, float* dx, int N, int T, int f0, int f1, hipStream_t stream) {
+    if (!dy || !HT4 || !xin4 || !W4 || !dZ4 || !dx || N <= 0 || T <= 0 || f0 < 0 || f1 > T || f0 >= f1) return TACO_EINVAL;
+    return highway4_bwd_launch(dy, HT4, xin4, W4, dZ4, dx, N * T, f1 - f0, T, f0, N * cdiv(f1 - f0, 32), stream);
 }

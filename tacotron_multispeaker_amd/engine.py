@@ -124,7 +124,13 @@ class Engine:
         # stream lands on which queue is the runtime's choice, so the engine does not assume it: _pick_streams() measures it once.
         pr = [int(x) for x in os.environ.get('TACO_PRIO', '0:0').split(':')]
         self.main_stream = torch.cuda.Stream(device=self.dev, priority=pr[0]) if pr[0] != 0 else None
-        picked = self._pick_streams(3, pr)
+        if pr[0] == pr[1]:
+            picked = self._pick_streams(3, pr[0])
+        else:
+            # TACO_PRIO=-1:0: the critical streams in the high-priority pool (the runtime keeps separate hardware queues per priority),
+            # the auxiliary stream in the normal one: still four active queues (the idle null stream shares the auxiliary one's pool)
+            picked = self._pick_streams(2, pr[0])
+            picked.append(self._pick_streams(1, pr[1], against=picked)[0])
         self.stream_b, self.stream_c = picked[0], picked[1]     # decoder pipeline stages (GRU1 / GRU2 or attention)
         self.side_streams = [picked[2]] + [torch.cuda.Stream(device=self.dev, priority=pr[1])
                                            for _ in range(max(1, int(os.environ.get('TACO_SIDE_STREAMS', '1'))) - 1)]
@@ -172,12 +178,13 @@ class Engine:
             best = min(best, (time.perf_counter() - t0) * 1e6)
         return best > 1.6 * self.PROBE_US
 
-    def _pick_streams(self, n, pr):
-        """n streams from torch's pool that are pairwise on different hardware queues and not on the current (main) stream's queue.
-        Falls back to the first pool streams when the runtime offers fewer queues (GPU_MAX_HW_QUEUES < 4) or TACO_STREAM_PROBE=0."""
+    def _pick_streams(self, n, priority, against=()):
+        """n streams from torch's pool that are pairwise on different hardware queues and not on the queue of the current (main)
+        stream nor of the streams in `against`.  Falls back to the first pool streams when the runtime offers fewer queues
+        (GPU_MAX_HW_QUEUES < 4) or TACO_STREAM_PROBE=0."""
         main = self.main_stream if self.main_stream is not None else torch.cuda.current_stream(self.dev)
-        cands = [torch.cuda.Stream(device=self.dev, priority=pr[0]) for _ in range(int(os.environ.get('TACO_STREAM_CANDIDATES', '12')))]
-        self._stream_pool, self._stream_classes = cands, None
+        cands = [torch.cuda.Stream(device=self.dev, priority=priority) for _ in range(int(os.environ.get('TACO_STREAM_CANDIDATES', '12')))]
+        self._stream_pool = cands
         if os.environ.get('TACO_STREAM_PROBE', '1') == '0':
             return cands[:n]
         with torch.cuda.device(self.dev):
@@ -185,7 +192,7 @@ class Engine:
             torch.cuda.synchronize(self.dev)
             chosen = []
             for c in cands:
-                if all(not self._serialised(c, o) for o in [main] + chosen):
+                if all(not self._serialised(c, o) for o in [main] + list(against) + chosen):
                     chosen.append(c)
                     if len(chosen) == n:
                         break
@@ -392,14 +399,26 @@ class Engine:
                 for a in arr:
                     lib.taco_col_sum(a.x, a.ldx, a.out, a.M, a.C, self.st)
 
-    def flush_side(self):
-        """Enqueue the pending weight-gradient work on the side stream.  Called right AFTER a persistent recurrence
-        kernel was launched on the main stream: that kernel occupies <= 128 CUs for ~1 ms, the GEMMs fill the rest;
-        between recurrences the critical-path GEMMs keep the machine to themselves."""
-        if not self._deferred:
-            return
+    def inputs_ready(self):
+        """Event on the current stream: everything the deferred weight-gradient descriptors queued so far read has been produced.
+        Record it BEFORE launching a recurrence kernel and hand it to flush_side() after the launch: the side stream then starts
+        beside the recurrence instead of behind it (round 3: the linear layer's dW ran after the 0.5 ms post-net biGRU BPTT
+        although 192 CUs were idle during it, the decoder's dW after the encoder biGRU BPTT)."""
         ev = torch.cuda.Event()
         ev.record()
+        return ev
+
+    def flush_side(self, ready=None):
+        """Enqueue the pending weight-gradient work on the side stream.  Called right AFTER a persistent recurrence
+        kernel was launched on the main stream: that kernel occupies <= 128 CUs for ~1 ms, the GEMMs fill the rest;
+        between recurrences the critical-path GEMMs keep the machine to themselves.  ready: inputs_ready() event taken before
+        that launch (default: an event recorded now, i.e. the side stream also waits for the kernel just launched)."""
+        if not self._deferred:
+            return
+        ev = ready
+        if ev is None or os.environ.get('TACO_FLUSH_BESIDE', '1') == '0':
+            ev = torch.cuda.Event()
+            ev.record()
         for ss in self.side_streams:
             ss.wait_event(ev)
         # runs of weight / bias gradient descriptors become grouped launches; with several side streams the runs are dealt
@@ -507,7 +526,55 @@ class Engine:
                         self.G(scope + '/bias'), dx, dx.stride(-2), M, C, T, pool, relu, self.st)
 
     # ---- CBHG (models/modules.py:35-74) ----------------------------------------------------------------------------
-    def cbhg_fwd(self, sc, x, N, T, cin, K, proj, lengths, training, bank_dstat=None):
+    # ---- frame-band pipelines behind the post-net biGRU (round 3) -------------------------------------------------------------
+    # The post-net biGRU is 640 dependent steps on 64 of 256 CUs, forward and again in BPTT (~0.5 ms each at C2), and what follows
+    # it is row-independent: linear layer -> L1 loss -> linear input gradient after the forward pass, input projection gradient ->
+    # highway stack BPTT after the backward pass.  Both directions sweep the whole sequence, so once the recurrence is past the
+    # middle, step p completes the frames [T - p, p): the recurrence is cut into a few chunk launches (state carried through a
+    # small buffer) and after each chunk the consumers of the frames it completed run on the auxiliary stream beside the next chunk.
+    # Only the last band (the sequence ends) is left when the recurrence finishes.
+
+    def _tail_chunks(self, T, training):
+        fr = os.environ.get('TACO_TAIL_PLAN', '0')          # measured: no gain at C2, off by default
+        if not training or T < int(os.environ.get('TACO_TAIL_MIN_T', '256')) or fr in ('', '0'):
+            return [(0, T)]
+        cuts = [0]
+        for f in fr.split(':'):
+            c = min(T, int(round(T * float(f) / 8)) * 8)
+            if c > cuts[-1] and c < T:
+                cuts.append(c)
+        cuts.append(T)
+        return list(zip(cuts[:-1], cuts[1:]))
+
+    @staticmethod
+    def _new_bands(T, q, p):
+        """frame ranges whose two directions are both done after step p, and were not after step q (q < p)"""
+        lo, hi = T - p, p
+        if hi <= lo:
+            return []
+        qlo, qhi = T - q, q
+        if qhi <= qlo:
+            return [(lo, hi)]
+        return [bd for bd in ((lo, qlo), (qhi, hi)) if bd[1] > bd[0]]
+
+    def _chunked_bigru(self, launch, T, chunks, tail):
+        """launch(s0, s1, pad) runs one chunk on the current stream; tail(bands) the consumers of completed frames on the auxiliary
+        stream.  Returns after the current stream has been made to wait for the auxiliary stream."""
+        cur = torch.cuda.current_stream()
+        aux = self.stream_d
+        pad = int(os.environ.get('TACO_TAIL_PAD', '150000')) if len(chunks) > 1 else 0
+        for (s0, s1) in chunks:
+            launch(s0, s1, pad)
+            bands = self._new_bands(T, s0, s1)
+            if tail is not None and bands:
+                ev = torch.cuda.Event(); ev.record(cur)
+                aux.wait_event(ev)
+                with torch.cuda.stream(aux):
+                    tail(bands)
+        if tail is not None:
+            cur.wait_stream(aux)
+
+    def cbhg_fwd(self, sc, x, N, T, cin, K, proj, lengths, training, bank_dstat=None, tail=None):
         """bank_dstat: the conv bank output (buffer sc/bank) and its batch-norm sums were produced piecewise by the caller."""
         M, C, st = N * T, K * 128, self.st
         B = self.buf(sc + '/bank', M, C)
@@ -561,12 +628,18 @@ class Engine:
         self.gemm(hw, self.P(sc + '/bigru/wx'), self.P(sc + '/bigru/bias'), XP, M, 128, 768)
         OUT = self.buf(sc + '/out', M, 256)
         RUC = self.buf(sc + '/ruc', 2, N, T, 384)
-        self._timed('biGRU(128) fwd (gru128_seq_fwd_k)', 2.0 * 2 * M * 128 * 384,
-                    lambda: lib.taco_gru128_seq_fwd(XP, 768, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
-                                                    self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC, N, T, 2, st))
+        chunks = self._tail_chunks(T, training) if tail is not None else [(0, T)]
+        state = self.buf(sc + '/gru_state', 2, N, 128)
+        self._chunked_bigru(
+            lambda s0, s1, pad: self._timed(
+                'biGRU(128) fwd (gru128_seq_fwd_k)', 2.0 * 2 * N * (s1 - s0) * 128 * 384,
+                lambda: lib.taco_gru128_seq_fwd(XP, 768, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
+                                                self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC, N, T, 2,
+                                                s0, s1, state, pad, self.st)),
+            T, chunks, tail)
         return OUT
 
-    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx, eager=False, after_proj2=None, bank_dx_later=False):
+    def cbhg_bwd(self, sc, x, dOUT, N, T, cin, K, proj, lengths, dx, eager=False, after_proj2=None, bank_dx_later=False, tail=False):
         """dOUT [M,256] gradient wrt the CBHG output; writes the gradient wrt the CBHG input x into dx [M,cin].
         eager: release the deferred weight-gradient launches to the side stream after every block (encoder: nothing
         latency-bound follows that they could disturb, and held back they would run as a serial tail after the main stream)."""
@@ -579,23 +652,56 @@ class Engine:
         OUT, RUC = b[sc + '/out'], b[sc + '/ruc']
         dXP = self.buf(sc + '/dxp', M, 768)
         HP, RH = self.buf(sc + '/hp', 2, M, 128), self.buf(sc + '/rh', 2, M, 128)
-        self._timed('biGRU(128) bwd (gru128_seq_bwd_k)', 2.0 * 2 * M * 128 * 384,
-                    lambda: lib.taco_gru128_seq_bwd(dOUT, 256, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
-                                                    self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC,
-                                                    dXP, 768, HP, RH, N, T, 2, st))
-        self.flush_side()
+        ready = self.inputs_ready() if self._deferred else None
+        dhw = self.buf(sc + '/dhw_a', M, 128)
+        other = self.buf(sc + '/dhw_b', M, 128)
+        hw_ins = [(b[sc + '/hwd'] if proj[1] != 128 else b[sc + '/hw0'])] + [b['%s/hw%d' % (sc, i)] for i in range(1, 4)]
+        dZs = [self.buf('%s/dZ%d' % (sc, i), M, 256) for i in range(1, 5)]      # one per layer: read later by the side-stream dW GEMM
+        pa = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+        chunks = self._tail_chunks(T, True) if (tail and self.fused_highway and M >= self.FUSED_HIGHWAY_MIN_ROWS) else [(0, T)]
+        banded = len(chunks) > 1
+        dHW0_b = self.buf(sc + '/dhw0', M, proj[1]) if (banded and proj[1] != 128) else None
+
+        def btail(bands):
+            # frames whose BPTT is complete in BOTH directions: gradient wrt the highway output, the highway stack's BPTT and (post-net)
+            # the 80 -> 128 dense layer's input gradient, all row-independent
+            for (f0, f1) in bands:
+                self._timed('dX GEMM (conv_gemm_nt2)', 2.0 * N * (f1 - f0) * 128 * 768,
+                            lambda: lib.taco_dense_rows_bwd_data(dXP, self.P(sc + '/bigru/wx'), dhw, N, T, f0, f1, 128, 768, 768, 768, 128, 0, self.st))
+                self._timed('highway x4 bwd (highway4_bwd_k)', 4 * 2.0 * N * (f1 - f0) * 128 * 256,
+                            lambda: lib.taco_highway4_bwd_rows(dhw, pa([b['%s/hwZ%d' % (sc, i)] for i in range(1, 5)]), pa(hw_ins),
+                                                               pa([self.P('%s/highway_%d/kernel' % (sc, i)) for i in range(1, 5)]), pa(dZs), other,
+                                                               N, T, f0, f1, self.st))
+                if dHW0_b is not None:
+                    lib.taco_dense_rows_bwd_data(other, self.P(sc + '/highway_dense/kernel'), dHW0_b, N, T, f0, f1, proj[1], 128, 128, 128,
+                                                 proj[1], 0, self.st)
+        state = self.buf(sc + '/gru_bstate', 2, N, 128)
+        first = [True]
+
+        def launch(s0, s1, pad):
+            self._timed('biGRU(128) bwd (gru128_seq_bwd_k)', 2.0 * 2 * N * (s1 - s0) * 128 * 384,
+                        lambda: lib.taco_gru128_seq_bwd(dOUT, 256, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
+                                                        self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC,
+                                                        dXP, 768, HP, RH, N, T, 2, s0, s1, state, pad, self.st))
+            if first[0]:
+                self.flush_side(ready)             # pending weight gradients start beside the first chunk
+                first[0] = False
+        self._chunked_bigru(launch, T, chunks, btail if banded else None)
         hw4 = b[sc + '/hw4']
         self.gemm_dw(hw4, dXP, self.G(sc + '/bigru/wx'), M, 128, 768)
         self.colsum(dXP, self.G(sc + '/bigru/bias'), M, 768)
         for di, d in enumerate(('fw', 'bw')):
             self.gemm_dw(HP[di], dXP[:, di * 384:], self.G('%s/bigru/%s_whg' % (sc, d)), M, 128, 256, ldx=128, lddy=768, ldw=256)
             self.gemm_dw(RH[di], dXP[:, di * 384 + 256:], self.G('%s/bigru/%s_whc' % (sc, d)), M, 128, 128, ldx=128, lddy=768, ldw=128)
-        dhw = self.buf(sc + '/dhw_a', M, 128)
-        self.gemm_dx(dXP, self.P(sc + '/bigru/wx'), dhw, M, 128, 768)
-        other = self.buf(sc + '/dhw_b', M, 128)
-        hw_ins = [(b[sc + '/hwd'] if proj[1] != 128 else b[sc + '/hw0'])] + [b['%s/hw%d' % (sc, i)] for i in range(1, 4)]
-        dZs = [self.buf('%s/dZ%d' % (sc, i), M, 256) for i in range(1, 5)]      # one per layer: read later by the side-stream dW GEMM
-        if self.fused_highway and M >= self.FUSED_HIGHWAY_MIN_ROWS:
+        if not banded:
+            self.gemm_dx(dXP, self.P(sc + '/bigru/wx'), dhw, M, 128, 768)
+        if banded:
+            for i in range(4, 0, -1):
+                self.gemm_dw(hw_ins[i - 1], dZs[i - 1], self.G('%s/highway_%d/kernel' % (sc, i)), M, 128, 256)
+                self.colsum(dZs[i - 1], self.G('%s/highway_%d/bias' % (sc, i)), M, 256)
+            dhw, other = other, dhw
+            flush(0)
+        elif self.fused_highway and M >= self.FUSED_HIGHWAY_MIN_ROWS:
             pa = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
             self._timed('highway x4 bwd (highway4_bwd_k)', 4 * 2.0 * M * 128 * 256,
                         lambda: lib.taco_highway4_bwd(dhw, pa([b['%s/hwZ%d' % (sc, i)] for i in range(1, 5)]), pa(hw_ins),
@@ -616,7 +722,8 @@ class Engine:
                 flush(0)
         if proj[1] != 128:
             dHW0 = self.buf(sc + '/dhw0', M, proj[1])
-            self.dense_bwd(b[sc + '/hw0'], dhw, sc + '/highway_dense', M, proj[1], 128, dx=dHW0)
+            # (banded: the input gradient was computed band by band above; the weight / bias gradients are deferred as always)
+            self.dense_bwd(b[sc + '/hw0'], dhw, sc + '/highway_dense', M, proj[1], 128, dx=None if banded else dHW0)
         else:
             dHW0 = dhw
         # proj_2 (no activation) -> proj_1 (relu) -> pooled bank (relu)
@@ -646,7 +753,9 @@ class Engine:
         return dx
 
     # ---- forward (models/tacotron.py:35-104) ------------------------------------------------------------------------
-    def forward(self, inputs, input_lengths, mel_targets, identities=None, training=True):
+    def forward(self, inputs, input_lengths, mel_targets, identities=None, training=True, linear_targets=None):
+        """linear_targets (training): the linear layer, its L1 loss and the loss gradient back to the post-net output are then
+        computed band by band behind the post-net biGRU (see _tail_chunks); loss() only adds the mel loss."""
         L, st = self.L, self.st
         N, Ti = inputs.shape
         To = mel_targets.shape[1]
@@ -742,10 +851,32 @@ class Engine:
         if not pipe_post:
             self.dense_fwd(gb[2]['D'], 'output_projection', MEL.view(Ms, nm * r), Ms, 256, nm * r)
         self._mark('decoder fwd')
-        POST = self.cbhg_fwd('post_cbhg', MEL.view(Mp, nm), N, To, nm, 8, (256, nm), None, training,
-                             bank_dstat=dst_post if pipe_post else None)
         LIN = self.buf('lin_out', N, To, self.nf)
-        self.gemm(POST, self.P('linear/kernel'), self.P('linear/bias'), LIN, Mp, 256, self.nf, ldw=L.ld_lin, ldy=self.nf)
+        self._tail_done = False
+        tail = None
+        if training and linear_targets is not None and len(self._tail_chunks(To, training)) > 1:
+            # linear layer (tacotron.py:101) + linear L1 loss (:132-135) + gradient wrt the post-net output, per band of frames
+            self.loss_sums = self.dslot(32)
+            dLIN, dPOST = self.buf('dlin', Mp, L.ld_lin), self.buf('dpost', Mp, 256)
+            Wl, bl = self.P('linear/kernel'), self.P('linear/bias')
+            w_all, w_pri = 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri)
+
+            def tail(bands):
+                POSTb = self._bufs['post_cbhg/out']
+                for (f0, f1) in bands:
+                    rows = N * (f1 - f0)
+                    self._timed('fwd GEMM (conv_gemm_nn2)', 2.0 * rows * 256 * self.nf,
+                                lambda: lib.taco_dense_rows_fwd(POSTb, Wl, bl, LIN, N, To, f0, f1, 256, self.nf, 256, L.ld_lin, self.nf, 0, 0, self.st))
+                    lib.taco_l1_loss_rows(LIN, self.nf, linear_targets, self.nf, dLIN, L.ld_lin, self.loss_sums[16:], N, To, f0, f1,
+                                          self.nf, self.npri, w_all, w_pri, self.st)
+                    self._timed('dX GEMM (conv_gemm_nt2)', 2.0 * rows * 256 * L.ld_lin,
+                                lambda: lib.taco_dense_rows_bwd_data(dLIN, Wl, dPOST, N, To, f0, f1, 256, L.ld_lin, L.ld_lin, L.ld_lin, 256, 0, self.st))
+            self.buf('post_cbhg/out', Mp, 256)               # exists before the closure runs
+            self._tail_done = True
+        POST = self.cbhg_fwd('post_cbhg', MEL.view(Mp, nm), N, To, nm, 8, (256, nm), None, training,
+                             bank_dstat=dst_post if pipe_post else None, tail=tail)
+        if not self._tail_done:
+            self.gemm(POST, self.P('linear/kernel'), self.P('linear/bias'), LIN, Mp, 256, self.nf, ldw=L.ld_lin, ldy=self.nf)
         self._mark('post-net fwd')
         self.mel_outputs, self.linear_outputs = MEL, LIN
         self.alignments = self._bufs['ALIGN'].view(N, S, Ti).transpose(1, 2)      # [N, Ti, S] (tacotron.py:104)
@@ -980,19 +1111,25 @@ class Engine:
         N, Ti, To, S = self.dims
         Mp, st = N * To, self.st
         self.linear_targets = linear_targets
-        self.loss_sums = self.dslot(32)                 # 2 losses x TACO_L1_REPL (8) replica pairs
+        tail_done = with_grad and getattr(self, '_tail_done', False)     # linear loss + gradient already taken behind the post-net biGRU
+        if not tail_done:
+            self.loss_sums = self.dslot(32)             # 2 losses x TACO_L1_REPL (8) replica pairs
         dMEL = self.buf('dmel_loss', Mp, self.nm) if with_grad else None
         dLIN = self.buf('dlin', Mp, self.L.ld_lin) if with_grad else None
         # the (small) mel loss runs beside the linear loss on the second decoder stream
         cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event(); ev.record(cur)
-        self.stream_b.wait_event(ev)
-        with torch.cuda.stream(self.stream_b):
+        if tail_done:
             lib.taco_l1_loss(self.mel_outputs, self.nm, self.mel_targets, self.nm, dMEL, self.nm, self.loss_sums, Mp, self.nm, 0,
-                             1.0 / (Mp * self.nm), 0.0, self.st)
-        lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin,
-                         self.loss_sums[16:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
-        cur.wait_stream(self.stream_b)
+                             1.0 / (Mp * self.nm), 0.0, st)
+        else:
+            ev = torch.cuda.Event(); ev.record(cur)
+            self.stream_b.wait_event(ev)
+            with torch.cuda.stream(self.stream_b):
+                lib.taco_l1_loss(self.mel_outputs, self.nm, self.mel_targets, self.nm, dMEL, self.nm, self.loss_sums, Mp, self.nm, 0,
+                                 1.0 / (Mp * self.nm), 0.0, self.st)
+            lib.taco_l1_loss(self.linear_outputs, self.nf, linear_targets, self.nf, dLIN, self.L.ld_lin,
+                             self.loss_sums[16:], Mp, self.nf, self.npri, 0.5 / (Mp * self.nf), 0.5 / (Mp * self.npri), st)
+            cur.wait_stream(self.stream_b)
         self.reg_sum = None
         if self.has_regularity:
             # loss_regularity (tacotron.py:140-171): value + gradient wrt the alignments, consumed by the attention BPTT
@@ -1032,7 +1169,8 @@ class Engine:
         self.gemm_dw(POST, dLIN, self.G('linear/kernel'), Mp, 256, self.nf, ldw=L.ld_lin)
         self.colsum(dLIN, self.G('linear/bias'), Mp, L.ld_lin)
         dPOST = self.buf('dpost', Mp, 256)
-        self.gemm_dx(dLIN, self.P('linear/kernel'), dPOST, Mp, 256, L.ld_lin, ldw=L.ld_lin)
+        if not getattr(self, '_tail_done', False):
+            self.gemm_dx(dLIN, self.P('linear/kernel'), dPOST, Mp, 256, L.ld_lin, ldw=L.ld_lin)
         chunks = self._chunks(N, S, Ti, self.pipe_chunks_bwd)[::-1]
         cur = torch.cuda.current_stream()
         dOUT = self.buf('dout', Ms, nm * r)
@@ -1045,7 +1183,7 @@ class Engine:
         pipe_post = self.post_pipe and len(chunks) > 1
         if pipe_post:
             dB, dHW0 = self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, None,
-                                     eager=os.environ.get('TACO_POST_EAGER', '0') == '1', bank_dx_later=True)
+                                     eager=os.environ.get('TACO_POST_EAGER', '0') == '1', bank_dx_later=True, tail=True)
             lib.taco_add(dHW0, b['dmel_loss'], dOUT, Mp * nm, 0, st)
             evs = torch.cuda.Event(); evs.record(cur)
             sd = self.stream_d
@@ -1072,7 +1210,7 @@ class Engine:
         else:
             dMELp = self.buf('dmel_post', Mp, nm)
             self.cbhg_bwd('post_cbhg', self.mel_outputs.view(Mp, nm), dPOST, N, To, nm, 8, (256, nm), None, dMELp,
-                          eager=os.environ.get('TACO_POST_EAGER', '0') == '1')
+                          eager=os.environ.get('TACO_POST_EAGER', '0') == '1', tail=True)
         if nb >= 2:
             self._bucket_ready(0)                       # post-net + linear
         self._mark('post-net bwd')
@@ -1117,10 +1255,24 @@ class Engine:
                 for nb, tab in self._attn_ptrs:
                     self._timed('attention recurrence bwd (attn_cluster_bwd_k)', 2 * self._attn_flops(nb, Ti, s1 - s0),
                                 lambda: lib.taco_attn_rnn_bwd(tab, self._dims(nb, S, Ti, s0, s1), self.st))
-            if ci == flush_at:
-                # post-net weight gradients fill the CUs the recurrences leave idle; released once the GRU BPTT chunks
-                # (which crowd the first attention chunks) are mostly done
-                self.flush_side()
+            if ci == flush_at or (ci == len(chunks) - 1 and os.environ.get('TACO_DEV_LOAD')):
+                if os.environ.get('TACO_DEV_LOAD'):
+                    # developer knob (interference study): a synthetic load takes the place of the weight-gradient flood here
+                    # "mode:wgs:lds_bytes:reps:megabytes"; combine with TACO_FLUSH_AT=-1 to move the real flood behind the decoder
+                    mode, wgs, ldsb, reps, mb = [int(x) for x in os.environ['TACO_DEV_LOAD'].split(':')]
+                    src = b['post_cbhg/bank']
+                    evd = torch.cuda.Event(); evd.record(cur)
+                    ss = self.side_streams[0]
+                    ss.wait_event(evd)
+                    dll = lib.load()
+                    dll.taco_dev_load.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_void_p]
+                    dll.taco_dev_load(src.data_ptr(), min(mb << 20, src.numel() * 4), reps, mode, wgs, ldsb, self.info.data_ptr() + 12,
+                                      ss.cuda_stream)
+                if ci == flush_at:
+                    # post-net weight gradients fill the CUs the recurrences leave idle; released once the GRU BPTT chunks
+                    # (which crowd the first attention chunks) are mostly done
+                    self.flush_side()
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
         self._mark('decoder bwd')
@@ -1224,7 +1376,7 @@ class Engine:
             self._train_step(inputs, input_lengths, mel_targets, linear_targets, identities)
 
     def _train_step(self, inputs, input_lengths, mel_targets, linear_targets, identities=None):
-        self.forward(inputs, input_lengths, mel_targets, identities, training=True)
+        self.forward(inputs, input_lengths, mel_targets, identities, training=True, linear_targets=linear_targets)
         self.loss(linear_targets)
         self.backward()
         self.allreduce_grads()

@@ -30,7 +30,7 @@ def run_engine_step(P, b, r, idn, apply=True, regularity=None):
     if regularity:
         eng.set_regularity(**regularity)
     i, l, m, lin, ids = dev_batch(b, eng.dev)
-    eng.forward(i, l, m, ids)
+    eng.forward(i, l, m, ids, linear_targets=lin)          # the call sequence of Engine.train_step
     eng.loss(lin)
     eng.backward()
     torch.cuda.synchronize()
@@ -127,6 +127,31 @@ def test_training_step_on_the_alternative_paths_matches_oracle(env, cfg, monkeyp
         assert words[1] == 0 and words[2] == 0
     else:
         assert words[2] > 0 and 0 <= words[1] <= words[2]
+
+
+@pytest.mark.parametrize('cfg,plan', [((4, 48, 120, 5, 0), '0.625:0.775:0.9'),     # chunks (0,72) (72,96) (96,104) (104,120)
+                                      ((3, 20, 135, 3, 2), '0.55:0.8'),            # odd T_out, bands that are not multiples of 32
+                                      ((2, 12, 70, 2, 0), '0.5:0.7:0.95')])        # first cut exactly at the middle: no band yet
+def test_post_net_bigru_frame_band_pipelines_match_oracle(cfg, plan, monkeypatch):
+    """The post-net biGRU cut into chunk launches (state carried through a buffer) with the consumers of the frames each chunk
+    completes running beside the next chunk: linear layer + L1 loss + linear input gradient after the forward pass
+    (taco_dense_rows_fwd, taco_l1_loss_rows, taco_dense_rows_bwd_data), input-projection gradient + highway-stack BPTT + 80->128
+    dense gradient after the backward pass (taco_highway4_bwd_rows).  BASELINE shapes enable it from T_out = 256; here it is forced
+    on small shapes and held, like every other path, to the float64 oracle: outputs, loss, every gradient tensor, the update."""
+    from oracle import tacotron_np as onp
+    monkeypatch.setenv('TACO_TAIL_MIN_T', '16')
+    monkeypatch.setenv('TACO_TAIL_PLAN', plan)
+    N, Ti, To, r, idn = cfg
+    from tacotron_multispeaker_amd.engine import Engine
+    monkeypatch.setattr(Engine, 'FUSED_HIGHWAY_MIN_ROWS', 1)    # the banded BPTT uses the fused highway kernel
+    assert len(Engine._tail_chunks(None, To, True)) >= 3
+    P = onp.init_params(seed=41, r=r, id_num=idn)
+    rng = np.random.RandomState(4)
+    for k in P:
+        if k.endswith(('/bias', '/beta')):
+            P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+    b = onp.synth_batch(N, Ti, To, r, seed=51, id_num=idn)
+    _oracle_step_compare(P, b, r, idn)
 
 
 @pytest.mark.parametrize('cfg', [(66, 14, 20, 5, 0), (2, 300, 30, 5, 0), (130, 10, 15, 5, 3)])
@@ -575,7 +600,13 @@ def test_empty_and_invalid_arguments_are_rejected():
     with pytest.raises(RuntimeError, match='-22'):
         lib.taco_conv_gemm_fwd(x, x, None, x, 16, 16, 8, 8, 1, 0, 6, 8, 8, 0, 0, stream())     # ld not a multiple of 4
     with pytest.raises(RuntimeError, match='-22'):
-        lib.taco_gru128_seq_fwd(None, 768, x, x, x, x, None, x, 256, x, 1, 1, 2, stream())     # null xp
+        lib.taco_gru128_seq_fwd(None, 768, x, x, x, x, None, x, 256, x, 1, 1, 2, 0, 1, None, 0, stream())     # null xp
+    with pytest.raises(RuntimeError, match='-22'):
+        lib.taco_gru128_seq_fwd(x, 768, x, x, x, x, None, x, 256, x, 1, 8, 2, 2, 6, None, 0, stream())        # a chunk without a state buffer
+    with pytest.raises(RuntimeError, match='-22'):
+        lib.taco_l1_loss_rows(x, 8, x, 8, None, 8, x, 2, 8, 5, 9, 8, 0, 1.0, 0.0, stream())                    # frames beyond T
+    with pytest.raises(RuntimeError, match='-22'):
+        lib.taco_spin_us(-1, stream())
 
 
 def test_train_py_end_to_end_with_feeder(tmp_path, monkeypatch):
