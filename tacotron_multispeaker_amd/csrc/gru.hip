@@ -87,20 +87,29 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
     float* ruc = p.ruc + ((long)dir * p.N + row) * p.T * 3 * H;
     float* orow = p.out + (long)row * p.T * p.ldo + dir * H;
 
+    // The step loop is BRANCH-FREE: every lane of a column's K-group computes the (identical) reduced sum, the activation and the
+    // stores -- a wave instruction costs the same with one active lane or 64, and duplicate stores of equal values are harmless.
+    // What it buys: with the stores inside `if (owner)` blocks the compiler could not count the memory operations behind the
+    // one-step-ahead prefetch loads and closed every step with `s_waitcnt vmcnt(0)`, i.e. waited for the write acknowledgements of
+    // the step's saved activations (round 3: 0.79 -> 0.6x us per step).
     auto tstep = [&](int s) { return dir == 0 ? s : p.T - 1 - s; };
-    float xg = 0.f, xc = 0.f;
+    // gate lanes: r columns write r*h into rh_l, u columns write u into u_l; one address computation, no branch
+    const bool is_r = gcol < H;
+    float* gdst = is_r ? (rh_l + LIDX(gcol)) : (u_l + (gcol - H));
+    const float* hsrc = h_l + LIDX(gcol & (H - 1));
+    float xg, xc;
     {
         const int t = tstep(p.s0);
-        if (kh == 0) xg = xrow[(long)t * p.ldxp + gcol];
-        if (kq == 0) xc = xrow[(long)t * p.ldxp + 2 * H + ccol];
+        xg = xrow[(long)t * p.ldxp + gcol];
+        xc = xrow[(long)t * p.ldxp + 2 * H + ccol];
     }
     for (int s = p.s0; s < p.s1; ++s) {
         const int t = tstep(s);
         const float ag = xg, ac = xc;
-        if (s + 1 < p.s1) {                             // prefetch the next step's input projection
-            const int tn = tstep(s + 1);
-            if (kh == 0) xg = xrow[(long)tn * p.ldxp + gcol];
-            if (kq == 0) xc = xrow[(long)tn * p.ldxp + 2 * H + ccol];
+        {                                               // prefetch the next step's input projection (the last step re-reads its own)
+            const int tn = tstep(min(s + 1, p.s1 - 1));
+            xg = xrow[(long)tn * p.ldxp + gcol];
+            xc = xrow[(long)tn * p.ldxp + 2 * H + ccol];
         }
         // ---- gates
         float a;
@@ -113,12 +122,11 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
             }
             a = (a2.x + a2.y) + (a3.x + a3.y);
         }
-        a = group_sum<KSG>(a);
-        if (kh == 0) {
+        a = group_sum<KSG>(a);                          // every lane of the group holds the sum
+        {
             const float g = fast_sigmoid(a + ag);
             ruc[(long)t * 3 * H + gcol] = g;
-            if (gcol < H) rh_l[LIDX(gcol)] = g * h_l[LIDX(gcol)];
-            else u_l[gcol - H] = g;
+            *gdst = is_r ? g * *hsrc : g;
         }
         lds_barrier();
         // ---- candidate + state update
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
             b = (b2.x + b2.y) + (b3.x + b3.y);
         }
         b = group_sum<KSC>(b);
-        if (kq == 0) {
+        {
             const float c = fast_tanh(b + ac);
             const float hprev = h_l[LIDX(ccol)];
             const float u = u_l[ccol];
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_fwd_k(GruSeq p) {
             const bool valid = t < len;
             ruc[(long)t * 3 * H + 2 * H + ccol] = c;
             orow[(long)t * p.ldo + ccol] = valid ? hn : 0.0f;
+            // the four lanes of a column sit in one wave: its read of hprev above is an earlier LDS instruction than this write
             h_l[LIDX(ccol)] = valid ? hn : hprev;
         }
         lds_barrier();
@@ -184,22 +193,23 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
     float* dxrow = p.dxp + (long)row * p.T * p.ldxp + xoff;
     float* hprow = p.hp + dn * p.T * H;
     float* rhrow = p.rh + dn * p.T * H;
-    const bool owner = jq == 0;
     float* dst = p.state ? p.state + dn * H : nullptr;
-    float dh = (p.s0 > 0 && owner) ? dst[k] : 0.0f;               // dh left by the previous chunk launch
+    float dh = p.s0 > 0 ? dst[k] : 0.0f;                          // dh left by the previous chunk launch
     // saved activations / incoming gradient of a step do not depend on the recurrence: fetched ONE STEP AHEAD into
-    // registers so that their HBM/L2 latency is off the dependent chain
+    // registers so that their HBM/L2 latency is off the dependent chain.  Like the forward kernel the loop is BRANCH-FREE (all JS
+    // lanes of a hidden index compute and store the same values; out-of-range steps load a clamped address and select zero), so the
+    // compiler can count the stores behind the prefetch loads instead of draining them every step (s_waitcnt vmcnt(0)).
     float pf_r = 0.f, pf_u = 0.f, pf_c = 0.f, pf_h = 0.f, pf_d = 0.f;
     auto prefetch = [&](int s) {
         const int t = dir == 0 ? p.T - 1 - s : s;
-        pf_r = pf_u = pf_c = pf_h = pf_d = 0.f;
-        if (owner && t < len) {
-            const float* q = ruc + (long)t * 3 * H;
-            pf_r = q[k]; pf_u = q[H + k]; pf_c = q[2 * H + k];
-            const int tp = dir == 0 ? t - 1 : t + 1;       // forward-order predecessor
-            if (tp >= 0 && tp < len) pf_h = orow[(long)tp * p.ldo + k];
-            pf_d = dorow[(long)t * p.lddo + k];
-        }
+        const int tl = min(t, max(len - 1, 0));
+        const float* q = ruc + (long)tl * 3 * H;
+        const float r_ = q[k], u_ = q[H + k], c_ = q[2 * H + k], d_ = dorow[(long)tl * p.lddo + k];
+        const int tp = dir == 0 ? t - 1 : t + 1;           // forward-order predecessor
+        const float h_ = orow[(long)min(max(tp, 0), p.T - 1) * p.ldo + k];
+        const bool v = t < len;
+        pf_r = v ? r_ : 0.f; pf_u = v ? u_ : 0.f; pf_c = v ? c_ : 0.f; pf_d = v ? d_ : 0.f;
+        pf_h = (v && tp >= 0 && tp < len) ? h_ : 0.f;
     };
     prefetch(p.s0);
 
@@ -207,12 +217,12 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
         const int t = dir == 0 ? p.T - 1 - s : s;          // reverse of the forward order
         const bool valid = t < len;
         const float r = pf_r, u = pf_u, c = pf_c, hprev = pf_h;
-        const float dhT = (owner && valid) ? dh + pf_d : 0.f;
-        if (s + 1 < p.s1) prefetch(s + 1);
+        const float dhT = valid ? dh + pf_d : 0.f;
+        prefetch(min(s + 1, p.s1 - 1));                    // (the last step re-reads its own)
         const float du = dhT * (hprev - c);
         float dh_new = valid ? dhT * u : dh;
         const float dcp = dhT * (1.0f - u) * (1.0f - c * c);
-        if (owner) dcp_l[LIDX(k)] = dcp;
+        dcp_l[LIDX(k)] = dcp;
         lds_barrier();
         // ---- drh[k] = sum_j dcp[j] * Wc[k][j]
         float drh;
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
             drh = (d2.x + d2.y) + (d3.x + d3.y);
         }
         drh = group_sum<JS>(drh);
-        if (owner) {
+        {
             dh_new += drh * r;
             const float dgr = drh * hprev * r * (1.0f - r);
             const float dgu = du * u * (1.0f - u);
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(NTH, NTH / 256) void gru128_seq_bwd_k(GruSeq p) {
         e = group_sum<JS>(e);
         dh = dh_new + e;
     }
-    if (p.s1 < p.T && owner) dst[k] = dh;
+    if (p.s1 < p.T) dst[k] = dh;
 }
 
 // TACO_GRU128_THREADS = 256 | 512 (default 512; measured: 256 threads = one wave per SIMD is 27 % SLOWER per step, see gru128_seq_fwd_k)
