@@ -531,7 +531,7 @@ __device__ __forceinline__ void gather_off(const u64* region, float* lds0, float
 // WLDS: the prenet-gradient weight slices (Wx^T 24 + W2^T 8 floats per thread) live in LDS instead of registers.  With all
 // 112 weight floats in VGPRs the compiler spills ~58 loop-invariant dwords to scratch and reloads ~50 of them EVERY step
 // (each an exposed ~300-cycle scratch load on the recurrence chain: 16.2 vs 12.2 us/step); 64 KiB of LDS removes that.
-// The register variant remains for long inputs whose key/memory tiles need the LDS (Ti > ~150).
+// The register variant remains for long inputs whose key/memory tiles need the LDS (Ti > 148).
 template <bool WLDS, int NT>
 __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -555,7 +555,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     float* a_l = ep_l + ((2 * Ti + 3) & ~3);       // [2*Ti] alignments of this step
     float* de_l = a_l + ((2 * Ti + 3) & ~3);       // [2*Ti] da -> de
     float* cp_l = de_l + ((2 * Ti + 3) & ~3);      // [8][64]
-    float* K_l = cp_l + 512;
+    float* st_l = cp_l + 512;                      // WLDS: [480] saved activations / external gradients of the NEXT step (see PFW below)
+    float* K_l = st_l + (WLDS ? 512 : 0);
     float* M_l = K_l + 2 * Ti * 32;
     for (int i = tid; i < 2 * Ti * 8; i += AT) {
         const int c4 = i & 7, t = (i >> 3) % Ti, row = (i >> 3) / Ti;
@@ -608,10 +609,69 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         dhc0 = p.dhcarry[(unsigned)rw[0] * 256u + jA]; dhc1 = p.dhcarry[(unsigned)rw[1] * 256u + jA];
         dcc0 = p.dctxcarry[(unsigned)rw[0] * 256u + jA]; dcc1 = p.dctxcarry[(unsigned)rw[1] * 256u + jA];
     }
-    // one-step-ahead prefetch registers, primed for s = S-1
+    // ---- PFW (WLDS variant): the prefetch WAVE.  The saved activations / external gradients of step s-1 come from HBM, and every
+    // granule poll of a wave (`s_waitcnt vmcnt(0)` to read the polled value) also waits for that wave's outstanding prefetch loads:
+    // with each lane fetching its own values one step ahead, the HBM latency sat on the dependent chain at the next poll (measured:
+    // 8.92 us per step, 8.06 with the loads removed).  Wave 7 (threads 448..511) takes part in NO vector gather (those use threads
+    // < 448), so after its last poll of the step (the da partials in X1) it fetches everything the workgroup needs for step s-1 --
+    // 7 x 64 + 32 + 64 + 2 Ti floats, coalesced, ~13 load instructions -- keeps it in registers while the step runs, and parks it in
+    // LDS in front of the step's last barrier; all lanes read their values from there at the top of the next step.
+    constexpr int NA = 2 * NT;                       // wave-loads of the 2 Ti alignments (NT = 2: Ti <= 128)
+    float wv_v[WLDS ? 7 : 1], wv_p2 = 0.f, wv_q = 0.f, wv_a[WLDS ? NA : 1];
+    // (pure loads, no select or branch on a loaded value: anything that consumes one makes the compiler wait for it -- and, loads
+    // returning in order, for every load before it -- right here on the chain; clamps on the ADDRESS side, selects at park time)
+    // Addresses are RUNNING 32-bit indices (one subtraction per step and tensor): formed per step as o * stride + lane offset the
+    // compiler used 64-bit multiply-adds whose addend register pairs overlapped the destinations of the loads just issued, and
+    // waited for them (s_waitcnt vmcnt(6) between the loads).
+    int wv_first = 0;                                  // the parked step is step 0 (no predecessor state: hp = 0)
+    unsigned ix_rj = 0, ix_hc = 0, ix_p2 = 0, ix_a[WLDS ? NA : 1];
+    if constexpr (WLDS) {
+        const int l = tid & 63, b = l >> 5, c = l & 31, l2 = l & 31;
+        const unsigned o = (unsigned)(rw[b] * S + p.s1 - 1);
+        ix_rj = o * 256u + 32 * w + c;
+        ix_hc = o * 512u + 32 * w + c;
+        ix_p2 = (unsigned)(rw[l2 >> 4] * S + p.s1 - 1) * 128u + 16 * w + (l2 & 15);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = min(l + 64 * i, 2 * Ti - 1), row = e >= Ti;
+            ix_a[i] = (unsigned)(rw[row] * S + p.s1 - 1) * (unsigned)Ti + (e - row * Ti);
+        }
+    }
+    auto stage_fetch = [&](int sidx) {                 // executed by ONE wave (lane = tid & 63); fetches step sidx, then points at sidx-1
+        wv_first = sidx == 0;
+        wv_v[0] = p.r[ix_rj]; wv_v[1] = p.u[ix_rj]; wv_v[2] = p.c[ix_rj];
+        wv_v[3] = p.hc[ix_hc - (sidx > 0 ? 512u : 0u)];
+        wv_v[4] = p.dhc[ix_hc]; wv_v[5] = p.dhc[ix_hc + 256u];
+        wv_v[6] = p.p1[ix_rj];
+        wv_p2 = p.p2[ix_p2];
+        wv_q = p.q[ix_rj];
+#pragma unroll
+        for (int i = 0; i < (WLDS ? NA : 1); ++i) wv_a[i] = p.align[ix_a[i]];
+    };
+    auto stage_next = [&]() {                          // every wave keeps the indices in step (uniform code, seven subtractions)
+        ix_rj -= 256u; ix_hc -= 512u; ix_p2 -= 128u;
+#pragma unroll
+        for (int i = 0; i < (WLDS ? NA : 1); ++i) ix_a[i] -= (unsigned)Ti;
+    };
+    auto stage_park = [&]() {                          // same wave: registers -> LDS (st_l, q_l, a_l)
+        const int l = tid & 63;
+#pragma unroll
+        for (int v = 0; v < (WLDS ? 7 : 1); ++v) st_l[v * 64 + l] = (v == 3 && wv_first) ? 0.f : wv_v[v];
+        if (l < 32) st_l[448 + l] = wv_p2;
+        q_l[l] = wv_q;
+#pragma unroll
+        for (int i = 0; i < (WLDS ? NA : 1); ++i) { const int e = l + 64 * i; if (e < 2 * Ti) a_l[e] = wv_a[i]; }
+    };
+    // one-step-ahead prefetch registers (register variant), primed for s = s1-1
     float pf_a = 0.f, pf_q = 0.f, pf_r[2] = {0, 0}, pf_u[2] = {0, 0}, pf_c[2] = {0, 0}, pf_hp[2] = {0, 0}, pf_dhe[2] = {0, 0},
           pf_dce[2] = {0, 0}, pf_p1[2] = {0, 0}, pf_p2[2] = {0, 0};
-    {
+    if constexpr (WLDS) {
+        if (tid >= AT - 64) {
+            stage_fetch(p.s1 - 1);
+            stage_park();
+        }
+        stage_next();
+    } else {
         const unsigned sl[2] = {(unsigned)(rw[0] * S + p.s1 - 1), (unsigned)(rw[1] * S + p.s1 - 1)};
         if (2 * Ti <= AT && tid < 2 * Ti) { const int row = tid >= Ti; pf_a = p.align[sl[row] * (unsigned)Ti + (tid - row * Ti)]; }
         if (tid < 64) pf_q = p.q[sl[tid >> 5] * 256u + 32 * w + (tid & 31)];
@@ -644,14 +704,24 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         asm volatile("" : "+v"(so[0]), "+v"(so[1]));   // opaque per-step offsets: no precomputed 64-bit addresses kept live
         // ---- this step's saved activations / external gradients were fetched ONE STEP AHEAD (registers), so their HBM
         //      latency is off the critical path; now issue the loads for step s-1
-        if (2 * Ti <= AT) { if (tid < 2 * Ti) a_l[tid] = pf_a; }
-        else for (int i = tid; i < 2 * Ti; i += AT) { const int row = i >= Ti; a_l[i] = p.align[so[row] * (unsigned)Ti + (i - row * Ti)]; }
-        if (tid < 64) q_l[tid] = pf_q;
         float r_[2], u_[2], c_[2], hp_[2], dhe[2], dce[2], p1v[2], p2v[2];
+        if constexpr (WLDS) {
+            // a_l / q_l / st_l were parked by the prefetch wave in front of the previous step's last barrier (or by the prologue)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            r_[b] = pf_r[b]; u_[b] = pf_u[b]; c_[b] = pf_c[b]; hp_[b] = pf_hp[b]; dhe[b] = pf_dhe[b]; dce[b] = pf_dce[b];
-            p1v[b] = pf_p1[b]; p2v[b] = pf_p2[b];
+            for (int b = 0; b < 2; ++b) {
+                const float* sp = st_l + b * 32 + cA;
+                r_[b] = sp[0]; u_[b] = sp[64]; c_[b] = sp[128]; hp_[b] = sp[192]; dhe[b] = sp[256]; dce[b] = sp[320]; p1v[b] = sp[384];
+                p2v[b] = st_l[448 + b * 16 + cB];
+            }
+        } else {
+            if (2 * Ti <= AT) { if (tid < 2 * Ti) a_l[tid] = pf_a; }
+            else for (int i = tid; i < 2 * Ti; i += AT) { const int row = i >= Ti; a_l[i] = p.align[so[row] * (unsigned)Ti + (i - row * Ti)]; }
+            if (tid < 64) q_l[tid] = pf_q;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                r_[b] = pf_r[b]; u_[b] = pf_u[b]; c_[b] = pf_c[b]; hp_[b] = pf_hp[b]; dhe[b] = pf_dhe[b]; dce[b] = pf_dce[b];
+                p1v[b] = pf_p1[b]; p2v[b] = pf_p2[b];
+            }
         }
         // ================= X1: total dctx (own slice), da partials =================
         if (pA == 0) {
@@ -689,6 +759,11 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             for (int k = 0; k < 4; ++k) sum += (half * 4 + k == w) ? e : val[k];
             const float tot2 = dpp_add<0xB1>(sum);
             if (half == 0) de_l[i] = tot2;                        // da[row][t]
+        }
+        if constexpr (WLDS) {
+            // the prefetch wave's last poll of this step is behind it: fetch step s-1 now, park it in front of the last barrier
+            if (tid >= AT - 64 && s > p.s0) stage_fetch(s - 1);
+            stage_next();
         }
         STAMP(2);
         lds_barrier();
@@ -793,8 +868,8 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         }
         lds_barrier();
         STAMP(9);
-        // ---- issue the loads for step s-1 (consumed at the top of the next iteration)
-        if (s > p.s0) {
+        // ---- (register variant) issue the loads for step s-1 (consumed at the top of the next iteration)
+        if (!WLDS && s > p.s0) {
             const unsigned sn[2] = {so[0] - 1u, so[1] - 1u};
             if (2 * Ti <= AT && tid < 2 * Ti) { const int row = tid >= Ti; pf_a = p.align[sn[row] * (unsigned)Ti + (tid - row * Ti)]; }
             if (tid < 64) pf_q = p.q[sn[tid >> 5] * 256u + 32 * w + (tid & 31)];
@@ -846,9 +921,13 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
             STAMP(12);
             gather_vec<32>(xDP1, dp1_l, dp1_l + PLEN(256), w, epoch, tid, p.err);
         }
+        if constexpr (WLDS) {
+            // a_l, q_l and the stage were last read in X2+X3 / at the top of THIS step; the barrier below publishes the next step's
+            if (tid >= AT - 64 && s > p.s0) stage_park();
+        }
         lds_barrier();
         STAMP(13);
-        if (s > p.s0) {
+        if (!WLDS && s > p.s0) {
             if (pA == 0) { pf_p1[0] = p.p1[(so[0] - 1u) * 256u + jA]; pf_p1[1] = p.p1[(so[1] - 1u) * 256u + jA]; }
             if (pB == 0) { pf_p2[0] = p.p2[(so[0] - 1u) * 128u + jB]; pf_p2[1] = p.p2[(so[1] - 1u) * 128u + jB]; }
         }
@@ -901,12 +980,12 @@ __global__ __launch_bounds__(256) void attn_hoisted_bwd_k(const float* __restric
 
 static size_t attn_cluster_bwd_smem(int Ti, bool wlds = false) {
     size_t f = 2 * PLEN(256) + 2 * PLEN(768) + 2 * PLEN(128) + 2 * PLEN(256) + 64 + 64 + 3 * ((2 * Ti + 3) & ~3) + 512 +
-               (size_t)4 * Ti * 32 + (wlds ? 8 * AT * 4 : 0);
+               (size_t)4 * Ti * 32 + (wlds ? 8 * AT * 4 + 512 : 0);
     return f * sizeof(float);
 }
 
 // which BPTT kernel a (N, Ti) launch runs: 0 = shape not held by the cluster path (per-step kernels), 1 = attn_cluster_bwd_k<true>
-// (prenet-gradient weight slices parked in LDS; fits while Ti <= ~152), 2 = attn_cluster_bwd_k<false> (all weights in registers; the
+// (prenet-gradient weight slices parked in LDS; fits while Ti <= 148), 2 = attn_cluster_bwd_k<false> (all weights in registers; the
 // key / memory tiles of long inputs need the LDS).  TACO_ATTN_NO_WLDS=1 forces variant 2 (tests).
 extern "C" int taco_attn_cluster_bwd_variant(int N, int Ti) {
     if (!taco_attn_cluster_supported(N, Ti)) return 0;

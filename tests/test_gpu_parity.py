@@ -205,13 +205,13 @@ def _oracle_step_compare(P, b, r, idn, gtol=TOL, apply=True, gabs=1e-6, regulari
 # (N, T_in, T_out, r, id_num, force register-weights variant, expected BPTT variant)
 @pytest.mark.parametrize('cfg', [(4, 200, 96, 2, 5, False, 2),      # C5-shaped: T_in 200, r 2, S 48 (4 pipeline chunks), multispeaker
                                  (2, 192, 120, 5, 0, False, 2),     # C2x-shaped: T_in 192, r 5, S 24
-                                 (2, 160, 40, 5, 0, False, 2),      # just past the LDS-weights limit (T_in 152)
+                                 (2, 152, 40, 5, 0, False, 2),      # just past the LDS-weights limit (T_in 148)
                                  (3, 256, 45, 5, 3, False, 2),      # near the LDS limit of the cluster path (~270)
-                                 (2, 152, 40, 5, 0, False, 1),      # last T_in of the LDS-weights variant
+                                 (2, 148, 40, 5, 0, False, 1),      # last T_in of the LDS-weights variant (prefetch wave + stage in LDS)
                                  (4, 40, 100, 5, 0, True, 2)])      # register-weights variant forced at a small T_in
 def test_attention_bptt_variants_long_inputs(cfg, monkeypatch):
     """attn_cluster_bwd_launch runs attn_cluster_bwd_k<true> (prenet-gradient weight slices in LDS) while they fit beside the
-    key / memory tiles (T_in <= 152) and attn_cluster_bwd_k<false> (all weight slices in registers) for T_in 153..~270 -- the
+    key / memory tiles (T_in <= 148) and attn_cluster_bwd_k<false> (all weight slices in registers) for T_in 149..~270 -- the
     kernel BASELINE configs C5 (T_in 200, r 2, max_iters 400) and C2x (T_in 192) use.  Full training step against the
     float64 oracle; the chunk pipeline is active (S >= 8)."""
     from oracle import tacotron_np as onp
