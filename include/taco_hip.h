@@ -169,6 +169,24 @@ int taco_gather_frames(const float* mel, float* frames, int N, int S, int r, int
  * state passes through HC (forward) and the DHCARRY / DCTXCARRY slots (backward)); whole sequence: s0 = 0, s1 = S */
 int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipStream_t stream);
 int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stream);
+/* The same for ONE chunk of a chunked BPTT with the chunk-to-chunk carries (dh, dctx at the boundary) handed over as granules
+ * instead of through memory between two launches: TACO_ATTN_CARRY_POST -- this launch publishes its final carries as granules;
+ * TACO_ATTN_CARRY_WAIT -- this launch (the chunk [s0, s1) with s1 < S) may be started on another stream BESIDE the launch of the
+ * later chunk [s1, ..): it counts its workgroups in a residency counter as they start, runs its prologue and then polls for the
+ * carries.  The caller uses that to have the last chunk resident before the one before it ends, so that no other work can take the
+ * CUs between two chunk launches (engine.py, round 3); taco_wait_count on the residency counter gates such work.  A WAIT launch
+ * needs a TACO_AP_XCHG buffer of its OWN (same size, zero-filled by the caller once per pass: two kernels running side by side
+ * must not share step-exchange slots) and carry_xchg = the TACO_AP_XCHG buffer of the POST launch (its carry region and counter
+ * are the ones used); carry_xchg = NULL otherwise. */
+#define TACO_ATTN_CARRY_POST 1
+#define TACO_ATTN_CARRY_WAIT 2
+int taco_attn_rnn_bwd_chunk(const void* const* ptrs, const int* dims, int carry_flags, void* carry_xchg, hipStream_t stream);
+/* index (in 8-byte slots) of the residency counter (an int) inside the TACO_AP_XCHG buffer of an (N, Ti) launch; workgroups per launch */
+int taco_attn_bwd_resident_slot(int N, int Ti);
+int taco_attn_bwd_workgroups(int N);
+/* one wave that waits until *counter >= target (bounded: sets err[0] after ~50 ms): orders work on a stream behind an event
+ * that only a running kernel can signal */
+int taco_wait_count(const int* counter, int target, int* err, hipStream_t stream);
 /* free-running inference decoder (reference models/helpers.py:7-38 TacoTestHelper, models/tacotron.py:86-94):
  * ptrs indexed by enum TacoInferPtr (all required), dims = {N, S = max_iters (row stride of the [N,S,*] outputs), Ti, r,
  * num_mels, s0, s1}: enqueues decoder steps [s0, s1); state carries over between calls through HC / OUT / H1 / H2.

@@ -18,6 +18,7 @@
 #include "xcd_granule.hpp"
 
 #define CW 8                 // workgroups per cluster
+#define TACO_CARRY_TAG 0x43590000u      // 'CY..': epochs of the carry granules = this + the step index of the chunk boundary
 // Diagnostic build (-DTACO_STAMP): thread 0 of workgroup 0 accumulates s_memtime deltas per phase and writes them behind
 // the exchange region (never read by the kernel); the shipped build contains no stamp.
 #ifdef TACO_STAMP
@@ -603,11 +604,30 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     const bool local = cluster_local(p.xchg + (long)nclus * per_clu + (long)cl * CW, w, p.err, reinterpret_cast<int*>(cp_l), tid, p.xcd_local,
                                      (unsigned)(p.S - p.s1));
 
+    // carry hand-over region behind the exchange regions and the placement granules: per cluster [dh | dctx][2 rows][256] granules,
+    // then ONE residency counter for the whole launch (taco_attn_rnn_bwd_chunk)
+    // A launch that WAITS runs beside the posting launch and must not share its step-exchange slots: with the L2-local granule
+    // form both kernels' clusters keep dirty lines of those slots in (possibly different) XCD L2s, and the posting kernel's
+    // write-back at its end can put an old epoch over a newer one in memory (seen as hand-off timeouts in 2 of 12 steps).  It
+    // therefore gets an exchange buffer of its own (p.xchg) and only the carry region / counter of the posting launch's buffer.
+    u64* cbase = p.carry_xchg ? p.carry_xchg : p.xchg;
+    u64* cX = cbase + (long)nclus * (per_clu + CW) + (long)cl * 1024;
+    int* resident = reinterpret_cast<int*>(cbase + (long)nclus * (per_clu + CW + 1024));
+    if ((p.carry_flags & TACO_ATTN_CARRY_WAIT) && tid == 0) atomicAdd(resident, 1);       // this workgroup is on its CU
     float dhc0 = 0.f, dhc1 = 0.f;      // dh carry   (owner lanes: pA == 0, index jA)
     float dcc0 = 0.f, dcc1 = 0.f;      // dctx carry (owner lanes: pA == 0, index jA)
     if (p.s1 < S && pA == 0) {         // chunked launch: state of the later chunk
-        dhc0 = p.dhcarry[(unsigned)rw[0] * 256u + jA]; dhc1 = p.dhcarry[(unsigned)rw[1] * 256u + jA];
-        dcc0 = p.dctxcarry[(unsigned)rw[0] * 256u + jA]; dcc1 = p.dctxcarry[(unsigned)rw[1] * 256u + jA];
+        if (p.carry_flags & TACO_ATTN_CARRY_WAIT) {
+            // this launch was started BESIDE the launch of the later chunk (so that it holds its CUs before that one lets go of
+            // its own): the carries arrive as granules tagged with the step they belong to, published by that launch's last step
+            const u64* const ptr[4] = {cX + jA, cX + 256 + jA, cX + 512 + jA, cX + 768 + jA};
+            float v[4];
+            get_g<4>(ptr, TACO_CARRY_TAG + (unsigned)p.s1, v, p.err);
+            dhc0 = v[0]; dhc1 = v[1]; dcc0 = v[2]; dcc1 = v[3];
+        } else {
+            dhc0 = p.dhcarry[(unsigned)rw[0] * 256u + jA]; dhc1 = p.dhcarry[(unsigned)rw[1] * 256u + jA];
+            dcc0 = p.dctxcarry[(unsigned)rw[0] * 256u + jA]; dcc1 = p.dctxcarry[(unsigned)rw[1] * 256u + jA];
+        }
     }
     // ---- PFW (WLDS variant): the prefetch WAVE.  The saved activations / external gradients of step s-1 come from HBM, and every
     // granule poll of a wave (`s_waitcnt vmcnt(0)` to read the polled value) also waits for that wave's outstanding prefetch loads:
@@ -941,10 +961,15 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
         STAMP(14);
         // (the next iteration's first LDS writes -- a_l, q_l, dctx_l -- are not read by X8: no barrier needed here)
     }
-    STAMP_OUT(p.xchg + (long)nclus * (per_clu + CW));
+    STAMP_OUT(p.xchg + (long)nclus * (per_clu + CW + 1024) + 1);
     if (p.s0 > 0 && pA == 0) {         // hand the carries to the launch of the previous chunk
         p.dhcarry[(unsigned)rw[0] * 256u + jA] = dhc0; p.dctxcarry[(unsigned)rw[0] * 256u + jA] = dcc0;
         p.dhcarry[(unsigned)rw[1] * 256u + jA] = dhc1; p.dctxcarry[(unsigned)rw[1] * 256u + jA] = dcc1;
+        if (p.carry_flags & TACO_ATTN_CARRY_POST) {         // ... which may already be resident and polling (agent scope: any placement)
+            const unsigned tag = TACO_CARRY_TAG + (unsigned)p.s0;
+            put_granule(cX + jA, tag, dhc0); put_granule(cX + 256 + jA, tag, dhc1);
+            put_granule(cX + 512 + jA, tag, dcc0); put_granule(cX + 768 + jA, tag, dcc1);
+        }
     }
 }
 
@@ -995,8 +1020,14 @@ extern "C" int taco_attn_cluster_bwd_variant(int N, int Ti) {
 }
 
 extern "C" int taco_attn_cluster_bwd_xchg_slots(int N, int Ti) {
-    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128 + CW) + 16;  // + CW placement granules per cluster; + 16 diagnostic stamp slots
+    // + CW placement granules and 1024 carry granules per cluster; + 1 residency counter; + 16 diagnostic stamp slots at the end
+    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128 + CW + 1024) + 1 + 16;
 }
+
+extern "C" int taco_attn_bwd_resident_slot(int N, int Ti) {
+    return ((N + 1) / 2) * (CW * 2 * Ti + 2 * 256 * 5 + 2 * 128 + CW + 1024);
+}
+extern "C" int taco_attn_bwd_workgroups(int N) { return CW * ((N + 1) / 2); }
 
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
     static DevMask attr_set[4] = {{0}, {0}, {0}, {0}};

@@ -19,5 +19,7 @@ struct AttnCluB {
     u64* xchg; int* err;
     int N, S, Ti, s0, s1;
     int xcd_local;
+    int carry_flags;                 // TACO_ATTN_CARRY_*: hand the chunk-to-chunk carries over as granules (taco_attn_rnn_bwd_chunk)
+    u64* carry_xchg;                 // exchange buffer whose carry region / residency counter is used (the POSTING launch's buffer)
 };
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st);

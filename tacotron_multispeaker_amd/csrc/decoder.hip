@@ -501,7 +501,11 @@ extern "C" int taco_attn_rnn_fwd(const void* const* ptrs, const int* dims, hipSt
 // Attention recurrence, backward.  Cluster path: also needs TACO_AP_DE [N,S,Ti], TACO_AP_DCTXS [N,S,256] and a dVPART of
 // [N*Ti,256]; dKEYS / dMEM / dVPART are then WRITTEN (not accumulated) by the hoisted reduction kernel.
 extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t st) {
-    if (!ptrs || !dims) return TACO_EINVAL;
+    return taco_attn_rnn_bwd_chunk(ptrs, dims, 0, nullptr, st);
+}
+
+extern "C" int taco_attn_rnn_bwd_chunk(const void* const* ptrs, const int* dims, int carry_flags, void* carry_xchg, hipStream_t st) {
+    if (!ptrs || !dims || (carry_flags & ~3)) return TACO_EINVAL;
     const int N = dims[0], S = dims[1], Ti = dims[2];
     if (N <= 0 || S <= 0 || Ti <= 0) return TACO_EINVAL;
     if (ptrs[TACO_AP_XCHG] && ptrs[TACO_AP_ERR] && ptrs[TACO_AP_DE] && ptrs[TACO_AP_DCTXS] && taco_attn_cluster_supported(N, Ti)) {
@@ -517,10 +521,14 @@ extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipSt
         p.da_ext = ptrs[TACO_AP_DAEXT] ? F(TACO_AP_DAEXT) : nullptr;
         p.xchg = (u64*)const_cast<void*>(ptrs[TACO_AP_XCHG]); p.err = (int*)const_cast<void*>(ptrs[TACO_AP_ERR]);
         p.dhcarry = G(TACO_AP_DHCARRY); p.dctxcarry = G(TACO_AP_DCTXCARRY);
-        p.N = N; p.S = S; p.Ti = Ti; p.s0 = dims[3]; p.s1 = dims[4];
+        p.N = N; p.S = S; p.Ti = Ti; p.s0 = dims[3]; p.s1 = dims[4]; p.carry_flags = carry_flags; p.carry_xchg = (u64*)carry_xchg;
         if (p.s0 < 0 || p.s1 > S || p.s0 >= p.s1) return TACO_EINVAL;
+        if ((carry_flags & TACO_ATTN_CARRY_WAIT) && (p.s1 == S || !carry_xchg || carry_xchg == (void*)p.xchg)) return TACO_EINVAL;   // no carries for
+                                                                                           // the first launch of a pass; own exchange buffer required
+        if ((carry_flags & TACO_ATTN_CARRY_POST) && p.s0 == 0) return TACO_EINVAL;      // the last one hands none over
         return attn_cluster_bwd_launch(p, G(TACO_AP_DKEYS), G(TACO_AP_DMEM), G(TACO_AP_DVPART), st);
     }
+    if (carry_flags) return TACO_EINVAL;                 // the per-step kernels run a pass in one call
     if (dims[3] != 0 || dims[4] != S) return TACO_EINVAL;
     return attn_rnn_bwd_steps(ptrs, dims, st);
 }

@@ -162,3 +162,19 @@ extern "C" int taco_spin_us(int us, hipStream_t stream) {
     hipLaunchKernelGGL(spin_us_k, dim3(1), dim3(64), 0, stream, (long)us * 100);
     TACO_RETURN_LAST();
 }
+
+// One wave that returns once *counter >= target: puts work of its stream behind something only a RUNNING kernel can signal (the
+// residency counter of taco_attn_rnn_bwd_chunk).  Bounded by the wall clock (~50 ms), then the error word is set.
+__global__ void wait_count_k(const int* __restrict__ counter, int target, int* err) {
+    const long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (wall_clock64() - t0 > 5000000L) { if (err) atomicExch(err, 4); break; }      // (4: told apart from a hand-off timeout in logs; any non-zero word invalidates the step)
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+
+extern "C" int taco_wait_count(const int* counter, int target, int* err, hipStream_t stream) {
+    if (!counter || target < 0) return TACO_EINVAL;
+    hipLaunchKernelGGL(wait_count_k, dim3(1), dim3(64), 0, stream, counter, target, err);
+    TACO_RETURN_LAST();
+}

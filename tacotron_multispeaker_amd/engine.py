@@ -1230,6 +1230,11 @@ class Engine:
         xg = {g: b['xchg_g%d' % g] for g in (1, 2)}
         Wp = self.P('concat_projection/kernel')
         flush_at = min(len(chunks) - 1, int(os.environ.get('TACO_FLUSH_AT', '99')))
+        early = (os.environ.get('TACO_ATTN_LAST_EARLY', '1') != '0' and len(chunks) > 1 and len(self._attn_ptrs) == 1 and not self.no_cluster
+                 and bool(lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti)))
+        if early:
+            xchg2 = self.buf('xchg_attn_b', (self._attn_keep['XCHG'].numel() + 1) & ~1, dtype=torch.int64)
+            lib.taco_zero(xchg2, xchg2.numel() * 8, st)         # this stream launches the kernel that uses it
         for ci, (s0, s1) in enumerate(chunks):
             if pipe_post:
                 cur.wait_event(piece_done[ci])
@@ -1250,11 +1255,25 @@ class Engine:
                 self.dense_rows_dx(dxp[1], self.P('decoder_gru_1/wx'), dD, N, S, s0, s1, 256, 768, 768, 256, 1)   # dY = dD1 + dxp1.Wx1^T
                 self.dense_rows_dx(dD, Wp, dHC, N, S, s0, s1, 512, 256, 256, 512, 0)                               # d[h|ctx] = dY.Wp^T
                 ev2 = torch.cuda.Event(); ev2.record(sb)
-            sc_.wait_event(ev2)
-            with torch.cuda.stream(sc_):
-                for nb, tab in self._attn_ptrs:
-                    self._timed('attention recurrence bwd (attn_cluster_bwd_k)', 2 * self._attn_flops(nb, Ti, s1 - s0),
-                                lambda: lib.taco_attn_rnn_bwd(tab, self._dims(nb, S, Ti, s0, s1), self.st))
+            # The LAST attention chunk is launched on this stream (GRU2 is done with it), BESIDE the chunk before it: it takes the CUs the
+            # GRU kernels have left, runs its prologue and polls for the carries, which the chunk before publishes as granules.  Without
+            # this the weight-gradient flood, released behind the last GRU1 chunk, found 128 empty CUs at the boundary between the last
+            # two attention launches and the last chunk took 800 us instead of 255 (rocprofv3 trace gpurun_out/r3_tr3).  The flood is
+            # held back until every workgroup of that launch has reported itself resident (taco_wait_count).
+            if early and ci == len(chunks) - 1:
+                cur.wait_event(ev2)
+                nb, tab = self._attn_ptrs[0]
+                tab2 = (ctypes.c_void_p * len(_AP))(*list(tab))         # the same tensors, an exchange buffer of its own
+                tab2[AP['XCHG']] = xchg2.data_ptr()
+                self._timed('attention recurrence bwd (attn_cluster_bwd_k)', 2 * self._attn_flops(nb, Ti, s1 - s0),
+                            lambda: lib.taco_attn_rnn_bwd_chunk(tab2, self._dims(nb, S, Ti, s0, s1), 2, self._attn_keep['XCHG'], self.st))
+            else:
+                sc_.wait_event(ev2)
+                with torch.cuda.stream(sc_):
+                    for nb, tab in self._attn_ptrs:
+                        self._timed('attention recurrence bwd (attn_cluster_bwd_k)', 2 * self._attn_flops(nb, Ti, s1 - s0),
+                                    lambda: lib.taco_attn_rnn_bwd_chunk(tab, self._dims(nb, S, Ti, s0, s1),
+                                                                        1 if (early and ci == len(chunks) - 2) else 0, None, self.st))
             if ci == flush_at or (ci == len(chunks) - 1 and os.environ.get('TACO_DEV_LOAD')):
                 if os.environ.get('TACO_DEV_LOAD'):
                     # developer knob (interference study): a synthetic load takes the place of the weight-gradient flood here
@@ -1271,8 +1290,17 @@ class Engine:
                                       ss.cuda_stream)
                 if ci == flush_at:
                     # post-net weight gradients fill the CUs the recurrences leave idle; released once the GRU BPTT chunks
-                    # (which crowd the first attention chunks) are mostly done
-                    self.flush_side()
+                    # (which crowd the first attention chunks) are done.  TACO_FLUSH_AFTER: gru2 = behind the last GRU2 chunk (this
+                    # stream), gru1 = behind the last GRU1 chunk and its projections (ev2: the flood no longer shares CUs with the
+                    # small projection GEMMs that gate the attention chunks, so those are launched back to back and the flood never
+                    # finds the attention CUs empty), attn = behind the launch point of the last attention chunk's predecessor
+                    after = os.environ.get('TACO_FLUSH_AFTER', 'gru1')
+                    if early and self._side_active:
+                        dll = lib.load()
+                        ctr = self._attn_keep['XCHG'].data_ptr() + 8 * dll.taco_attn_bwd_resident_slot(min(N, self.ATTN_ROWS), Ti)
+                        wgs = dll.taco_attn_bwd_workgroups(min(N, self.ATTN_ROWS))
+                        self._deferred.insert(0, lambda: lib.taco_wait_count(ctr, wgs, self.err, self.st))
+                    self.flush_side(ready=ev2 if (after == 'gru1' and len(chunks) > 1) else None)
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
         self._mark('decoder bwd')
