@@ -49,7 +49,14 @@ from tacotron_multispeaker_amd import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')    # {family: {"bytes_per_launch": ..., "source": ...}}
+TRAFFIC_FILE = os.path.join('profiles', 'r03_pmc_traffic.json')    # {family: {"bytes_per_launch": ..., "source": ...}}
+KERNEL_STATS_FILE = os.path.join('profiles', 'r03_step_c2_kernel_stats.csv')   # rocprofv3 --kernel-trace --stats of the same workload
+# kernel-name fragment of every timed family in that file
+FAMILY_KERNELS = {'dW GEMM (conv_gemm_tn2_group)': 'conv_gemm_tn2_group', 'dX GEMM (conv_gemm_nt2)': 'conv_gemm_nt2', 'fwd GEMM (conv_gemm_nn2)': 'conv_gemm_nn2',
+                  'attention recurrence bwd (attn_cluster_bwd_k)': 'attn_cluster_bwd_k', 'attention recurrence fwd (attn_cluster_fwd_k)': 'attn_cluster_fwd_k',
+                  'decoder GRU(256) bwd (gru256_cluster_bwd_k)': 'gru256_cluster_bwd_k', 'decoder GRU(256) fwd (gru256_cluster_fwd_k)': 'gru256_cluster_fwd_k',
+                  'biGRU(128) bwd (gru128_seq_bwd_k)': 'gru128_seq_bwd_k', 'biGRU(128) fwd (gru128_seq_fwd_k)': 'gru128_seq_fwd_k',
+                  'highway x4 bwd (highway4_bwd_k)': 'highway4_bwd_k', 'highway x4 fwd (highway4_fwd_k)': 'highway4_fwd_k'}
 
 
 def step_flops(N, Ti, To, r, E_in=256):
@@ -108,6 +115,18 @@ def kernel_families(eng, run_step, steps=5):
     traffic = {}
     if os.path.exists(os.path.join(ROOT, TRAFFIC_FILE)):
         traffic = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+    # rocprofv3's own durations of the same kernels (first wave start -> last wave end), from the committed --kernel-trace --stats
+    # summary of the same workload.  The live HIP-event bracket above also contains the time a launch waits on its stream for CUs
+    # (a persistent launch needs 128 empty ones) and for the events its stream waits on, so it reads 10-25 % longer for the
+    # recurrence chunks; `frac` (contract: measured live) uses the events, `frac_rocprof` the profiler's average duration.
+    prof = {}
+    if os.path.exists(os.path.join(ROOT, KERNEL_STATS_FILE)):
+        import csv
+        for r in csv.DictReader(open(os.path.join(ROOT, KERNEL_STATS_FILE))):
+            for famname, key in FAMILY_KERNELS.items():
+                if key in r['Name']:
+                    a = prof.setdefault(famname, [0, 0.0])
+                    a[0] += int(r['Calls']); a[1] += float(r['TotalDurationNs'])
     out = []
     for name, f in fam.items():
         tf = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
@@ -118,6 +137,13 @@ def kernel_families(eng, run_step, steps=5):
                         avg_launch_us=f['ms'] / f['launches'] * 1e3, flops_per_launch=f['flops'] / f['launches'],
                         achieved=tf, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=tf / PEAK_FP32_MFMA_TFLOPS,
                         traffic=tr.get('bytes_per_launch'), traffic_source=tr.get('source')))
+        # (only where the profile holds exactly the launches timed here: the small row-blocked projection GEMMs of the decoder
+        # pipeline are launched untimed, so the GEMM families of the profile average over more, shorter launches)
+        if name in prof and prof[name][0] and abs(prof[name][0] / 6.0 - f['launches'] / steps) < 0.5:
+            us = prof[name][1] / prof[name][0] / 1e3
+            # the committed profile has the same launches per step, so FLOPs per launch carry over
+            out[-1].update(rocprof_avg_launch_us=us, frac_rocprof=f['flops'] / f['launches'] / (us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                           rocprof_source=KERNEL_STATS_FILE)
     out.sort(key=lambda d: -d['ms_per_step'])
     return out
 
@@ -443,7 +469,9 @@ def main():
             out['error'] = 'a persistent cluster kernel reported a hand-off timeout: the timed steps are INVALID'
         if fams is not None:
             out['roofline'] = dict(fams[0], timing='HIP events around every launch of the family on its stream, 5 eager steps of the '
-                                                   'same workload after the timed region')
+                                                   'same workload after the timed region; frac_rocprof: same FLOPs over the average '
+                                                   'duration of the kernel in the committed rocprofv3 summary (the event bracket also holds '
+                                                   'the wait for CUs and for the stream\'s event dependencies)')
             out['kernel_families'] = fams[1:]
         else:
             out['roofline'] = None
