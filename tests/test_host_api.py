@@ -141,3 +141,46 @@ def test_engine_fails_loudly_without_gpu():
     from tacotron_multispeaker_amd.engine import Engine
     with pytest.raises(RuntimeError, match='no CPU path'):
         Engine()
+
+
+def test_frame_bands_behind_the_bigru_partition_the_sequence(monkeypatch):
+    """Engine._tail_chunks / _new_bands (host logic of the frame-band pipelines): the chunk cuts cover [0, T) in order, and the
+    bands reported after each chunk -- frames both directions of the biGRU have passed -- are disjoint and cover every frame
+    exactly once, whatever the plan."""
+    from tacotron_multispeaker_amd.engine import Engine
+    monkeypatch.setenv('TACO_TAIL_MIN_T', '16')
+    for plan, Ts in (('0.625:0.775:0.9', (120, 640, 135, 801)), ('0.5:0.7:0.95', (70, 64)), ('0.55:0.8', (135, 33)), ('0.7', (640,))):
+        monkeypatch.setenv('TACO_TAIL_PLAN', plan)
+        for T in Ts:
+            chunks = Engine._tail_chunks(None, T, True)
+            assert chunks[0][0] == 0 and chunks[-1][1] == T and all(a[1] == b[0] for a, b in zip(chunks[:-1], chunks[1:]))
+            seen = np.zeros(T, dtype=int)
+            for (q, p) in chunks:
+                for (f0, f1) in Engine._new_bands(T, q, p):
+                    assert 0 <= f0 < f1 <= T
+                    # complete after step p: the forward direction has done frames < p, the backward direction frames >= T - p
+                    assert f1 <= p and f0 >= T - p
+                    seen[f0:f1] += 1
+            assert (seen == 1).all(), (plan, T, chunks)
+    monkeypatch.setenv('TACO_TAIL_PLAN', '0')
+    assert Engine._tail_chunks(None, 640, True) == [(0, 640)]          # off by default
+    monkeypatch.setenv('TACO_TAIL_PLAN', '0.7')
+    assert Engine._tail_chunks(None, 640, False) == [(0, 640)]         # inference never chunks
+
+
+def test_checkpoint_layout_description_and_signature():
+    """The named layout a checkpoint stores (models/tacotron.py: reference synthesizer.py:23-25 recovers id_num from
+    model/inference/embedding_id): entries are named, ordered by offset, and the signature tells layouts apart."""
+    from tacotron_multispeaker_amd.params import ParamLayout
+    from models.tacotron import checkpoint_id_num
+    a, b, c = ParamLayout(id_num=0, r=5), ParamLayout(id_num=460, r=5), ParamLayout(id_num=0, r=2)
+    assert len({a.signature(), b.signature(), c.signature()}) == 3 and a.signature() == ParamLayout(id_num=0, r=5).signature()
+    d = b.describe()
+    names = [n for n, _, _ in d]
+    assert names[0] == 'embedding' and names[1] == 'embedding_id' and 'bn:post_cbhg/proj_2/moving_variance' in names
+    tr = [(n, o, s) for n, o, s in d if not n.startswith('bn:')]
+    assert all(x[1] < y[1] for x, y in zip(tr[:-1], tr[1:]))           # flat offsets ascend in creation order
+    assert tr[-1][1] + int(np.prod(tr[-1][2])) <= b.total
+    assert b.TF_SCOPE == 'model/inference'
+    assert checkpoint_id_num({'layout': {'entries': d, 'id_num': 460}}) == 460
+    assert checkpoint_id_num({'layout': {'entries': a.describe(), 'id_num': 0}}) == 0
