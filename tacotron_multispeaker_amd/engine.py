@@ -920,14 +920,19 @@ class Engine:
             raise RuntimeError('persistent cluster kernels would not be co-resident: %d / %d workgroups in one launch' % (attn, gru))
         return attn + 2 * gru <= budget
 
-    def _chunks(self, N, S, Ti, k=None):
+    def _chunks(self, N, S, Ti, k=None, plan_env='TACO_CHUNK_PLAN'):
         """Step ranges for the chunk-pipelined decoder (needs the cluster path); [(0, S)] = no pipelining."""
         k = k or self.pipe_chunks
         if k <= 1 or S < 2 * k or self.no_cluster or not lib.load().taco_attn_cluster_supported(min(N, self.ATTN_ROWS), Ti):
             return [(0, S)]
         if not self._check_residency(N, Ti) and os.environ.get('TACO_PIPE_OVERSUBSCRIBE', '0') != '1':
             return [(0, S)]          # the three launches of a pipeline stage would not all be resident: run them one at a time
-        plan = os.environ.get('TACO_CHUNK_PLAN', '')
+        plan = os.environ.get(plan_env, '') or os.environ.get('TACO_CHUNK_PLAN', '')
+        if not plan and plan_env == 'TACO_CHUNK_PLAN_BWD' and S >= 120 and k == 4:
+            # BPTT processes the chunks last-in-time first: a short first chunk (GRU2 -> GRU1 -> attention lead-in) and growing ones
+            # behind it.  Measured (scripts/dev_ab.py, round 3): C2 (S 128) 7.07 -> 7.01 ms, C5 (S 400) 12.04 -> 11.68 ms against the
+            # forward plan; C4 (S 96) 5.32 -> 5.38 ms, so shorter sequences keep the forward plan.
+            plan = '48:44:26:10'
         if plan:                                       # explicit relative chunk lengths, e.g. "40,36,28,16,8" (tuning aid)
             w = [float(x) for x in plan.split(':')]
             cuts = [0]
@@ -1171,7 +1176,7 @@ class Engine:
         dPOST = self.buf('dpost', Mp, 256)
         if not getattr(self, '_tail_done', False):
             self.gemm_dx(dLIN, self.P('linear/kernel'), dPOST, Mp, 256, L.ld_lin, ldw=L.ld_lin)
-        chunks = self._chunks(N, S, Ti, self.pipe_chunks_bwd)[::-1]
+        chunks = self._chunks(N, S, Ti, self.pipe_chunks_bwd, plan_env='TACO_CHUNK_PLAN_BWD')[::-1]
         cur = torch.cuda.current_stream()
         dOUT = self.buf('dout', Ms, nm * r)
         D2 = b['D2']

@@ -795,10 +795,11 @@ def test_pipelined_submit_collect_and_snapshot():
             got.append((out[0], out[1], p.mel_loss, p.linear_loss, p.learning_rate, p.max_gradient_norm, t))
     out = p.collect(tickets[0])
     got.append((out[0], out[1], p.mel_loss, p.linear_loss, p.learning_rate, p.max_gradient_norm, tickets[0]))
-    for r_, g_ in zip(ref, got):
+    for si, (r_, g_) in enumerate(zip(ref, got)):
         assert g_[0] == r_[0]
         for x, y in zip(r_[1:], g_[1:6]):
-            assert abs(x - y) < 2e-4 * abs(x)       # atomics reorder fp32 sums from launch to launch; 4 steps at lr 1e-3 amplify it
+            # atomics reorder fp32 sums from launch to launch (1e-6 on step 1); every further step at lr 1e-3 amplifies the difference
+            assert abs(x - y) < (1e-5 if si == 0 else 1e-3) * abs(x)
     snap = got[1][6].state_dict()
     assert int(snap['global_step'].item()) == 2 and checkpoint_id_num(snap) == 4
     assert snap['layout']['tf_scope'] == 'model/inference' and any(n == 'embedding_id' for n, _, _ in snap['layout']['entries'])
