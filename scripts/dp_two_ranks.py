@@ -54,6 +54,58 @@ def parent(a):
     return 0 if rc == 0 else 1
 
 
+def train_mode(a):
+    """train.py itself with two ranks on the one GPU (gloo transport): toy dataset, 8 steps, checkpoints every 4.  Exercises the
+    per-step agreement of the replicas (before a step is enqueued, after it is collected), rank-0 checkpoints behind a barrier and
+    the pipelined submit / collect loop under data parallelism."""
+    import json
+    import tempfile
+    import numpy as np
+    tmp = tempfile.mkdtemp(prefix='taco_dp_train_')
+    rng = np.random.RandomState(0)
+    lines = []
+    for i in range(16):
+        T = 23 + 3 * (i % 5)
+        paths = []
+        for kind, shape in (('spec', (T, 1025)), ('mel', (T, 80)), ('wav', (T * 250,))):
+            p = os.path.join(tmp, '%s-%d.npy' % (kind, i))
+            np.save(p, rng.rand(*shape).astype(np.float32))
+            paths.append(p)
+        lines.append(repr(paths + ['{%s}' % ' '.join('<sym%d>' % rng.randint(0, 7000) for _ in range(4 + i % 7)), i % 3]))
+    meta = os.path.join(tmp, 'toy_id_num_3.txt')
+    open(meta, 'w', encoding='utf-8').write('\n'.join(lines) + '\n')
+    json.dump({'TOY': meta}, open(os.path.join(tmp, 'train_npy_data_dict.json'), 'w'))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, TACO_ALLOW_SHARED_GPU='1', TACO_DIST_BACKEND='gloo', RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'train.py'), '--base_dir', os.path.join(tmp, 'logs'), '--train_data', 'TOY',
+                                       '--description', 'toy', '--hparams', 'batch_size=4,outputs_per_step=5,decay_learning_rate=false,initial_learning_rate=0.001',
+                                       '--max_steps', '8', '--checkpoint_interval', '4', '--summary_interval', '4'],
+                                      env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs, rc = [], 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=a.timeout)
+        except subprocess.TimeoutExpired:
+            p.kill(); out, _ = p.communicate(); out += '\n[parent] rank killed at the time limit\n'
+        outs.append(out); rc = rc or p.returncode
+    logf = os.path.join(tmp, 'logs', 'logs-tacotron-toy', 'train.log')
+    log = open(logf).read() if os.path.exists(logf) else ''
+    steps = [int(l.split('Step')[1].split('[')[0]) for l in log.splitlines() if 'avg_sec/step' in l]
+    ck = sorted(f for f in os.listdir(os.path.dirname(logf))) if log else []
+    ok = (rc == 0 and sorted(steps) == sorted(list(range(1, 9)) * 2) and log.count('Saving checkpoint to:') == 2
+          and 'Exiting due to exception' not in log and 'model.ckpt-4' in ck and 'model.ckpt-8' in ck and log.count('Summary at step') == 4)
+    text = ''.join('---- rank %d (exit %s), last lines ----\n%s\n' % (i, procs[i].returncode, '\n'.join(o.splitlines()[-6:])) for i, o in enumerate(outs))
+    text += 'steps logged by the two ranks: %s\ncheckpoints: %s\nTRAIN RESULT: %s\n' % (sorted(steps), ck, 'OK' if ok else 'FAILED')
+    print(text, flush=True)
+    if a.log:
+        with open(a.log, 'a') as f:
+            f.write(text)
+    return 0 if ok else 1
+
+
 def child(a):
     sys.path.insert(0, ROOT)
     import warnings
@@ -170,5 +222,8 @@ if __name__ == '__main__':
     ap.add_argument('--port', type=int, default=0)
     ap.add_argument('--log', default='')
     ap.add_argument('--timeout', type=float, default=540.0)
+    ap.add_argument('--train', action='store_true', help='run train.py with two ranks instead of the engine-level check')
     a = ap.parse_args()
-    sys.exit(parent(a) if a.rank < 0 else child(a))
+    if a.rank >= 0:
+        sys.exit(child(a))
+    sys.exit(train_mode(a) if a.train else parent(a))

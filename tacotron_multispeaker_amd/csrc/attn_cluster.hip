@@ -973,34 +973,57 @@ __global__ __launch_bounds__(AT, 2) void attn_cluster_bwd_k(AttnCluB p) {
     }
 }
 
-// Hoisted reductions over the S steps (fully parallel, one workgroup per (n,t), thread = feature d):
+// Hoisted reductions over the S steps (fully parallel, thread = feature d):
 //   dMEM[n,t,d]  = sum_s a[n,s,t] * dctx[n,s,d]                                   (gradient through the attention values)
 //   dKEYS[n,t,d] = v[d] * sum_s de[n,s,t] * (1 - tanh^2(keys[n,t,d] + q[n,s,d]))  (tanh tile recomputed, never stored)
 //   dvpart[n*Ti+t, d] = sum_s de[n,s,t] * tanh(...)                               (attention_v gradient partials)
+// One workgroup per (n, tile of HT positions t): q[n,s,:] and dctx[n,s,:] are loaded once per step and used for all HT positions (one
+// workgroup per (n,t) re-read them T_in times from L2: 1 GB per launch at C2, 90 us alone and 290 us beside the weight-gradient flood,
+// on the critical path between the attention BPTT and the encoder backward).
+#define HT 8
 __global__ __launch_bounds__(256) void attn_hoisted_bwd_k(const float* __restrict__ keys, const float* __restrict__ q,
                                                          const float* __restrict__ align, const float* __restrict__ de,
                                                          const float* __restrict__ dctx, const float* __restrict__ v,
                                                          float* __restrict__ dkeys, float* __restrict__ dmem,
                                                          float* __restrict__ dvpart, int S, int Ti) {
-    const int n = blockIdx.y, t = blockIdx.x, d = threadIdx.x;
-    const long nt = (long)n * Ti + t;
-    const float kd = keys[nt * 256 + d];
-    float am = 0.f, ak = 0.f, av = 0.f;
-    const float* ap = align + (long)n * S * Ti + t;
-    const float* ep = de + (long)n * S * Ti + t;
+    const int n = blockIdx.y, t0 = blockIdx.x * HT, d = threadIdx.x;
+    float kd[HT], am[HT], ak[HT], av[HT];
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+        const int t = min(t0 + j, Ti - 1);                 // a ragged last tile recomputes position Ti-1 and does not store it
+        kd[j] = keys[((long)n * Ti + t) * 256 + d];
+        am[j] = 0.f; ak[j] = 0.f; av[j] = 0.f;
+    }
+    const float* ap = align + (long)n * S * Ti;
+    const float* ep = de + (long)n * S * Ti;
     const float* qp = q + (long)n * S * 256 + d;
     const float* cp = dctx + (long)n * S * 256 + d;
-#pragma unroll 4
+#pragma unroll 2
     for (int s = 0; s < S; ++s) {
-        const float a = ap[(long)s * Ti], e = ep[(long)s * Ti];
-        const float th = fast_tanh(kd + qp[(long)s * 256]);
-        am = fmaf(a, cp[(long)s * 256], am);
-        ak = fmaf(e, 1.f - th * th, ak);
-        av = fmaf(e, th, av);
+        const float qv = qp[(long)s * 256], cv = cp[(long)s * 256];
+        const float* as = ap + (long)s * Ti;
+        const float* es = ep + (long)s * Ti;
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+            const int t = min(t0 + j, Ti - 1);
+            const float a = as[t], e = es[t];              // wave-uniform addresses: scalar loads
+            const float th = fast_tanh(kd[j] + qv);
+            am[j] = fmaf(a, cv, am[j]);
+            ak[j] = fmaf(e, 1.f - th * th, ak[j]);
+            av[j] = fmaf(e, th, av[j]);
+        }
     }
-    dmem[nt * 256 + d] = am;
-    dkeys[nt * 256 + d] = ak * v[d];
-    dvpart[nt * 256 + d] = av;
+    const float vd = v[d];
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+        const int t = t0 + j;
+        if (t < Ti) {
+            const long nt = (long)n * Ti + t;
+            dmem[nt * 256 + d] = am[j];
+            dkeys[nt * 256 + d] = ak[j] * vd;
+            dvpart[nt * 256 + d] = av[j];
+        }
+    }
 }
 
 static size_t attn_cluster_bwd_smem(int Ti, bool wlds = false) {
@@ -1048,7 +1071,7 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
     else if (small) hipLaunchKernelGGL((attn_cluster_bwd_k<false, 2>), grid, dim3(AT), smem, st, q);
     else hipLaunchKernelGGL((attn_cluster_bwd_k<false, 5>), grid, dim3(AT), smem, st, q);
     if (p.s0 == 0)       // all chunks done: reduce over the S steps
-        hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3(p.Ti, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
+        hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3((p.Ti + HT - 1) / HT, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
                            dkeys, dmem, dvpart, p.S, p.Ti);
     TACO_RETURN_LAST();
 }

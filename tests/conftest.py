@@ -26,6 +26,8 @@ def pytest_collection_finish(session):
     try:
         p = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'dp_two_ranks.py'), '--log', log, '--timeout', '420'],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=480)
-        session.config._dp_two_ranks = (p.returncode, p.stdout)
+        q = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'dp_two_ranks.py'), '--train', '--log', log, '--timeout', '300'],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=360)
+        session.config._dp_two_ranks = (p.returncode or q.returncode, p.stdout + q.stdout)
     except Exception as e:       # noqa: BLE001 -- the test reports it
         session.config._dp_two_ranks = (-1, 'could not run scripts/dp_two_ranks.py: %r' % (e,))

@@ -954,6 +954,9 @@ def test_two_rank_data_parallel_through_the_engine(request):
     assert rc == 0, out[-4000:]
     assert out.count('PASS') == 2 and 'RESULT: OK' in out
     assert out.count('bucket order [0, 1, 2, 3]') == 6
+    # and train.py itself with two ranks (toy dataset, 8 steps, checkpoints every 4): the replicas agree before every enqueue and after
+    # every collect, rank 0 writes the checkpoints, both ranks log every step and leave in order
+    assert 'TRAIN RESULT: OK' in out
 
 
 def test_changing_batch_shapes_reuse_the_workspace():

@@ -45,7 +45,11 @@ def train(log_dir, args):
     torch.set_num_threads(4)         # no torch CPU compute on the path: keep the intra-op pool (sized by the HOST's CPU count) out of the way
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        backend = os.environ.get('TACO_DIST_BACKEND', 'nccl')      # gloo: two ranks on ONE GPU (scripts/dp_two_ranks.py --train)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     coord = Coordinator()
     if args.data_type != 'npy':
@@ -105,7 +109,9 @@ def train(log_dir, args):
         submitting = True
 
         def may_submit():
-            if not submitting or coord.should_stop() or len(inflight) >= 2:
+            # only state that is identical on every rank (agreed flags, step counters): the ranks must run the same sequence of
+            # agreements; what a rank knows alone (its coordinator, its feeder) goes INTO the agreement below
+            if not submitting or len(inflight) >= 2:
                 return False
             return not (args.max_steps and (next_step > args.max_steps or steps_run + len(inflight) >= args.max_steps))
 
@@ -113,14 +119,15 @@ def train(log_dir, args):
             while may_submit():
                 # replicas agree BEFORE a step is enqueued (it contains the gradient all-reduce: a rank that enqueued it while
                 # another rank has no batch would wait for that rank forever)
-                failure = 0
-                try:
-                    have = model.next_batch_ready()
-                except Exception as e:          # feeder / staging error on this rank
-                    log('Exiting due to exception: %s' % e)
-                    traceback.print_exc()
-                    coord.request_stop(e)
-                    have, failure = False, 1
+                failure, have = 0, False
+                if not coord.should_stop():
+                    try:
+                        have = model.next_batch_ready()
+                    except Exception as e:      # feeder / staging error on this rank
+                        log('Exiting due to exception: %s' % e)
+                        traceback.print_exc()
+                        coord.request_stop(e)
+                        failure = 1
                 failure, missing = agree(failure, 0 if have else 1)
                 if failure or missing:
                     submitting = False
@@ -191,6 +198,12 @@ def train(log_dir, args):
     finally:
         coord.request_stop()
         model.stop()
+        if world > 1:
+            try:                                  # leave the process group in order (its threads must not outlive the interpreter)
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+            except Exception:                     # noqa: BLE001 -- a failed peer may already be gone
+                pass
 
 
 def main():
