@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def parent(a):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, TACO_ALLOW_SHARED_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--rank', str(r), '--port', str(port)], env=env,
+    extra = ['--rccl'] if a.rccl else []
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--rank', str(r), '--port', str(port)] + extra, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs, rc = [], 0
     deadline = time.time() + a.timeout
@@ -114,8 +115,14 @@ def child(a):
     import torch
     import torch.distributed as dist
     rank, world = a.rank, 2
-    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % a.port, rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev_index = rank if a.rccl else 0
+    if a.rccl:          # two DEVICES, the product transport (RCCL over xGMI); needs a box with >= 2 GPUs
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % a.port, rank=rank, world_size=world,
+                                device_id=torch.device('cuda', dev_index))
+    else:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % a.port, rank=rank, world_size=world)
+        torch.cuda.set_device(0)
     from oracle import tacotron_np as onp, tacotron_torch as ot          # checker only
     from tacotron_multispeaker_amd import dp
     from tacotron_multispeaker_amd.engine import Engine
@@ -129,14 +136,14 @@ def child(a):
 
     dev_ok = True
     try:
-        probe = torch.ones(8, device='cuda')
+        probe = torch.ones(8, device='cuda:%d' % dev_index)
         dist.all_reduce(probe)
         torch.cuda.synchronize()
         dev_ok = bool(probe[0].item() == world)
     except Exception as e:                                                  # this gloo build does not take device tensors
         dev_ok = False
         say('gloo on device tensors unavailable (%s): staging buckets through pinned host memory' % type(e).__name__)
-    oks = [torch.tensor([1 if dev_ok else 0])]
+    oks = [torch.tensor([1 if dev_ok else 0], device='cuda:%d' % dev_index if a.rccl else 'cpu')]
     dist.all_reduce(oks[0], op=dist.ReduceOp.MIN)
     dev_ok = bool(oks[0].item())
 
@@ -160,14 +167,15 @@ def child(a):
             self.works[i] = W()
             self.order.append(i)
 
-    eng = Engine(r=r, id_num=idn, named_params=P, device='cuda:0')
+    eng = Engine(r=r, id_num=idn, named_params=P, device='cuda:%d' % dev_index)
     eng.world = world
     if not dev_ok:
         eng._exchange = HostStagedExchange(eng.grads, dp.bucket_ranges(eng.L, 4), world)
     assert eng._gru256_pad(6) == 0, 'the GRU(256) isolation pad must be off under data parallelism'
+    assert a.rccl or os.environ.get('TACO_ALLOW_SHARED_GPU') == '1'
 
     def to_dev(b):
-        t = lambda k, dt: torch.tensor(b[k], device='cuda', dtype=dt)
+        t = lambda k, dt: torch.tensor(b[k], device=eng.dev, dtype=dt)
         return (t('inputs', torch.int32), t('input_lengths', torch.int32), t('mel_targets', torch.float32),
                 t('linear_targets', torch.float32), t('identities', torch.int32))
 
@@ -198,18 +206,19 @@ def child(a):
             ok = ok and worst[0] < 1e-5 and gn < 1e-4
         same = True
         for name in ('params', 'm', 'v'):
-            mine_t = getattr(eng, name).cpu()
+            mine_t = getattr(eng, name) if a.rccl else getattr(eng, name).cpu()
             got = [torch.zeros_like(mine_t) for _ in range(world)]
             dist.all_gather(got, mine_t)
             same = same and all(torch.equal(got[0], t) for t in got)
-        bn = eng.bn.cpu()
+        bn = eng.bn if a.rccl else eng.bn.cpu()
         gb = [torch.zeros_like(bn) for _ in range(world)]
         dist.all_gather(gb, bn)
         say('step %d  replicas bit-identical (params, m, v): %s   BN moving stats differ per replica: %s'
             % (step + 1, same, not torch.equal(gb[0], gb[1])))
         ok = ok and same and not torch.equal(gb[0], gb[1])
         ok = ok and int(eng.global_step.item()) == step + 1
-    say('collective transport: %s' % ('gloo on the device gradient buffer' if dev_ok else 'gloo via pinned host staging (script only)'))
+    say('collective transport: %s' % ('RCCL, one device per rank' if a.rccl else 'gloo on the device gradient buffer' if dev_ok
+                                      else 'gloo via pinned host staging (script only)'))
     say('PASS' if ok else 'FAIL')
     dist.barrier()
     dist.destroy_process_group()
@@ -223,6 +232,7 @@ if __name__ == '__main__':
     ap.add_argument('--log', default='')
     ap.add_argument('--timeout', type=float, default=540.0)
     ap.add_argument('--train', action='store_true', help='run train.py with two ranks instead of the engine-level check')
+    ap.add_argument('--rccl', action='store_true', help='two devices and the nccl (RCCL) backend instead of two ranks on one device over gloo')
     a = ap.parse_args()
     if a.rank >= 0:
         sys.exit(child(a))

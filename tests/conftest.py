@@ -28,6 +28,13 @@ def pytest_collection_finish(session):
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=480)
         q = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'dp_two_ranks.py'), '--train', '--log', log, '--timeout', '300'],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=360)
-        session.config._dp_two_ranks = (p.returncode or q.returncode, p.stdout + q.stdout)
+        rc, out = p.returncode or q.returncode, p.stdout + q.stdout
+        import torch
+        if torch.cuda.device_count() >= 2:          # (counting devices does not initialise the GPU) two devices: the RCCL transport too
+            r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'dp_two_ranks.py'), '--rccl', '--timeout', '300'],
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=360)
+            rc, out = rc or r2.returncode, out + r2.stdout.replace('PASS', 'PASS(rccl)').replace('RESULT: OK', 'RESULT(rccl): OK').replace(
+                'bucket order [0, 1, 2, 3]', 'bucket order(rccl) [0, 1, 2, 3]')
+        session.config._dp_two_ranks = (rc, out)
     except Exception as e:       # noqa: BLE001 -- the test reports it
         session.config._dp_two_ranks = (-1, 'could not run scripts/dp_two_ranks.py: %r' % (e,))
