@@ -1,12 +1,12 @@
 """HBM traffic per launch of the timed kernel families from the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_step.sh
-(set4 / set5) -> profiles/r02_pmc_traffic.json, which bench.py quotes as `roofline.traffic`.
+(set4 / set5) -> profiles/rNN_pmc_traffic.json, which bench.py quotes as `roofline.traffic`.
 Units per MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request -> x 2.
 usage: python scripts/pmc_traffic.py <pmc dir> [steps=3] [out.json]"""
 import collections, csv, glob, json, os, sys
 
 root = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
-out = sys.argv[3] if len(sys.argv) > 3 else os.path.join('profiles', 'r02_pmc_traffic.json')
+out = sys.argv[3] if len(sys.argv) > 3 else os.path.join('profiles', 'r03_pmc_traffic.json')
 FAMILIES = collections.OrderedDict([
     ('dW GEMM (conv_gemm_tn2_group)', 'conv_gemm_tn2_group'), ('dX GEMM (conv_gemm_nt2)', 'conv_gemm_nt2'),
     ('fwd GEMM (conv_gemm_nn2)', 'conv_gemm_nn2'), ('attention recurrence bwd (attn_cluster_bwd_k)', 'attn_cluster_bwd_k'),
@@ -14,7 +14,7 @@ FAMILIES = collections.OrderedDict([
     ('decoder GRU(256) bwd (gru256_cluster_bwd_k)', 'gru256_cluster_bwd_k'), ('decoder GRU(256) fwd (gru256_cluster_fwd_k)', 'gru256_cluster_fwd_k'),
     ('biGRU(128) bwd (gru128_seq_bwd_k)', 'gru128_seq_bwd_k'), ('biGRU(128) fwd (gru128_seq_fwd_k)', 'gru128_seq_fwd_k'),
     ('highway x4 bwd (highway4_bwd_k)', 'highway4_bwd_k'), ('highway x4 fwd (highway4_fwd_k)', 'highway4_fwd_k')])
-SRC = ('profiles/r02_pmc_traffic.json <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %d eager C2 steps incl. the first, '
+SRC = (out + ' <- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %d eager C2 steps incl. the first, '
        'scripts/pmc_step.sh + scripts/pmc_traffic.py); KiB x 1024, FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request)' % steps)
 
 
