@@ -269,6 +269,46 @@ def train_loop_legs(model, eng, cfg, steps, warmup):
     return out
 
 
+def dp_machinery_leg(eng, pool, steps):
+    """What the data-parallel event graph costs on ONE GPU: the same eager steps with the engine told world = 2 over a ONE-rank RCCL
+    communicator (no byte travels, all-reduce over one rank is the identity): four buckets launched out of band on the communication
+    stream behind their producers, the optimizer waiting for them, no GRU(256) isolation pad.  Not a scaling number -- RCCL over xGMI
+    with real peers is unmeasured in this pipeline -- but the part of the N > 1 step that can be measured here."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return None
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+    try:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=eng.dev)
+    except Exception as e:       # noqa: BLE001
+        return {'error': 'one-rank RCCL communicator unavailable: %r' % (e,)}
+    try:
+        eng.world = 2
+        eng.exposed_events = []
+
+        def one(i):
+            b = pool[i % len(pool)]
+            eng.train_step(b[0], b[1], b[2], b[3], b[4])
+        for i in range(5):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        ex = float(np.mean([e0.elapsed_time(e1) for e0, e1 in eng.exposed_events[-steps:]]))
+        order = list(eng._exchange.order)
+    finally:
+        eng.world = 1
+        eng.exposed_events = None
+        eng._exchange = None
+        dist.destroy_process_group()
+    return {'ms_per_step': ms, 'allreduce_wait_ms': ex, 'bucket_order': order,
+            'note': 'world assumed 2 over a one-rank RCCL communicator on one GPU: event graph, comm stream, no GRU(256) pad; no bytes travel'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -487,6 +527,7 @@ def main():
             out['cpu_baseline'] = None
         if world == 1 and not a.no_train_loop:
             out.update(train_loop_legs(model, eng, cfg, a.steps, a.warmup))
+            out['dp_machinery'] = dp_machinery_leg(eng, pool, a.steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
