@@ -1012,3 +1012,50 @@ def test_model_api_synthesis_mode():
     assert tuple(m.alignments.shape) == (1, 6, 4)
     assert bool(torch.isfinite(m.linear_outputs).all())
     importlib.reload(H)
+
+
+def test_synthesizer_wrapper_from_a_training_checkpoint(tmp_path, monkeypatch):
+    """reference synthesizer.py:13-58: Synthesizer().load(checkpoint) recovers the speaker count from the checkpoint, synthesize()
+    decodes free-running on the GPU and turns the linear spectrogram into a wav on the CPU.  The checkpoint is one train.py would
+    write (two steps of a 3-speaker model); the decode of the wrapper equals Engine.infer on the same weights."""
+    import importlib
+    import hparams as H
+    importlib.reload(H)
+    from models import create_model
+    from models.tacotron import GlobalStep
+    from oracle import tacotron_np as onp
+    H.hparams.parse('outputs_per_step=5,griffin_lim_iters=3')
+    b = onp.synth_batch(3, 10, 30, 5, seed=90, id_num=3)
+    m = create_model('tacotron', H.hparams)
+    m.initialize(b['inputs'], b['input_lengths'], b['mel_targets'], b['linear_targets'], identities=b['identities'], id_num=3, seed=4)
+    m.add_loss(); m.add_optimizer(GlobalStep())
+    for _ in range(2):
+        m.run_step()
+    ck = str(tmp_path / 'model.ckpt-2')
+    torch.save(m.state_dict(), ck)
+    import synthesizer
+    importlib.reload(synthesizer)
+    syn = synthesizer.Synthesizer()
+    syn.load(ck)
+    assert syn.id_num == 3
+    monkeypatch.setattr(synthesizer.hparams, 'max_iters', 12)          # 12 decoder steps = 60 frames: keeps Griffin-Lim short
+    text = '{%s}' % ' '.join('<sym%d>' % k for k in (5, 17, 300, 42, 7))
+    wav_path = str(tmp_path / 'out.wav')
+    def synth():
+        return syn.synthesize(text, 1, path=wav_path, path_align=str(tmp_path / 'align.npy'))
+    # synthesize() sets max_iters through hparams at load(); decode length is what infer ran
+    out = synth()
+    assert out == b'' and os.path.getsize(wav_path) > 44
+    from scipy.io import wavfile
+    sr, wav = wavfile.read(wav_path)
+    assert sr == 20000 and wav.dtype == np.int16 and np.abs(wav).max() > 0
+    S = syn.model.engine.linear_outputs.shape[1] // 5
+    assert len(wav) == (S * 5 - 1) * 250 and syn.alignment.shape[1] == S
+    # same weights, same ids -> the engine of the training model decodes the same spectrogram
+    import text as T
+    seq = T.text_to_sequence2(text, ['basic_cleaners'])[:-1]
+    e = m.engine
+    dev = lambda a, dt: torch.tensor(a, device=e.dev, dtype=dt)
+    e.infer(dev([seq], torch.int32), dev([len(seq)], torch.int32), dev([1], torch.int32), max_iters=S)
+    assert rel(syn.model.engine.linear_outputs.cpu().numpy(), e.linear_outputs.cpu().numpy()) < 1e-5
+    importlib.reload(H)

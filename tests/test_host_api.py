@@ -184,3 +184,31 @@ def test_checkpoint_layout_description_and_signature():
     assert b.TF_SCOPE == 'model/inference'
     assert checkpoint_id_num({'layout': {'entries': d, 'id_num': 460}}) == 460
     assert checkpoint_id_num({'layout': {'entries': a.describe(), 'id_num': 0}}) == 0
+
+
+def test_cpu_audio_helpers_round_trip_and_griffin_lim():
+    """util/audio.py (synthesis only; north_star keeps Griffin-Lim on the CPU): STFT with the reference's parameters
+    (util/audio.py:114-118: n_fft 2048, hop 250, window 1000 at 20 kHz) inverts exactly, Griffin-Lim reduces the spectral error
+    of a random-phase start, de-normalisation follows the reference's constants."""
+    import copy
+    import importlib
+    import hparams as H
+    importlib.reload(H)
+    from util import audio
+    importlib.reload(audio)
+    hp = H.hparams
+    assert audio.stft_parameters(hp) == (2048, 250, 1000)
+    t = np.arange(hp.sample_rate // 2) / hp.sample_rate
+    y = 0.5 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 1320 * t)
+    S = audio.stft(y, hp)
+    assert S.shape == (1025, 1 + len(y) // 250)
+    yr = audio.istft(S, hp)
+    n = min(len(y), len(yr))
+    assert np.abs(y[:n] - yr[:n]).max() < 1e-12
+    few, more = copy.copy(hp), copy.copy(hp)
+    few.griffin_lim_iters, more.griffin_lim_iters = 1, 25
+    err = lambda g: np.linalg.norm(np.abs(audio.stft(g, hp))[:, :S.shape[1]] - np.abs(S)) / np.linalg.norm(np.abs(S))
+    assert err(audio.griffin_lim(np.abs(S), more)) < err(audio.griffin_lim(np.abs(S), few)) < 1.0
+    # a spectrogram that is 1.0 everywhere is ref_level_db above 0 dB: amplitude 10^(20/20) = 10 before the power law
+    flat = audio.inv_spectrogram(np.ones((1025, 8)), few)
+    assert np.isfinite(flat).all() and len(flat) == 7 * 250
