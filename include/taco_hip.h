@@ -177,15 +177,21 @@ int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipStream_t stre
  * CUs between two chunk launches (engine.py, round 3); taco_wait_count on the residency counter gates such work.  A WAIT launch
  * needs a TACO_AP_XCHG buffer of its OWN (same size, zero-filled by the caller once per pass: two kernels running side by side
  * must not share step-exchange slots) and carry_xchg = the TACO_AP_XCHG buffer of the POST launch (its carry region and counter
- * are the ones used); carry_xchg = NULL otherwise. */
+ * are the ones used); carry_xchg = NULL otherwise.
+ * TACO_ATTN_NO_REDUCE -- the launch of the chunk with s0 == 0 does NOT enqueue the reduction over the steps behind itself
+ * (dKEYS / dMEM / dVPART from the per-step DE / DCTXS of ALL chunks): a WAIT launch ends after the carries of its predecessor
+ * were published, which is before that predecessor's kernel -- on another stream -- has retired and its last stores are ordered;
+ * the caller joins the two streams and then calls taco_attn_bwd_reduce. */
 #define TACO_ATTN_CARRY_POST 1
 #define TACO_ATTN_CARRY_WAIT 2
+#define TACO_ATTN_NO_REDUCE 4
 int taco_attn_rnn_bwd_chunk(const void* const* ptrs, const int* dims, int carry_flags, void* carry_xchg, hipStream_t stream);
+int taco_attn_bwd_reduce(const void* const* ptrs, const int* dims, hipStream_t stream);
 /* index (in 8-byte slots) of the residency counter (an int) inside the TACO_AP_XCHG buffer of an (N, Ti) launch; workgroups per launch */
 int taco_attn_bwd_resident_slot(int N, int Ti);
 int taco_attn_bwd_workgroups(int N);
-/* one wave that waits until *counter >= target (bounded: sets err[0] after ~50 ms): orders work on a stream behind an event
- * that only a running kernel can signal */
+/* one wave that waits until *counter >= target (bounded: sets err[0] after ~0.5 s): orders work on a stream behind an event
+ * that only a running kernel can signal; enqueue it only after the launch that signals the counter has been issued */
 int taco_wait_count(const int* counter, int target, int* err, hipStream_t stream);
 /* free-running inference decoder (reference models/helpers.py:7-38 TacoTestHelper, models/tacotron.py:86-94):
  * ptrs indexed by enum TacoInferPtr (all required), dims = {N, S = max_iters (row stride of the [N,S,*] outputs), Ti, r,

@@ -1070,8 +1070,13 @@ int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float*
     else if (wlds) hipLaunchKernelGGL((attn_cluster_bwd_k<true, 5>), grid, dim3(AT), smem, st, q);
     else if (small) hipLaunchKernelGGL((attn_cluster_bwd_k<false, 2>), grid, dim3(AT), smem, st, q);
     else hipLaunchKernelGGL((attn_cluster_bwd_k<false, 5>), grid, dim3(AT), smem, st, q);
-    if (p.s0 == 0)       // all chunks done: reduce over the S steps
-        hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3((p.Ti + HT - 1) / HT, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
-                           dkeys, dmem, dvpart, p.S, p.Ti);
+    if (p.s0 == 0 && !(p.carry_flags & TACO_ATTN_NO_REDUCE))       // all chunks done: reduce over the S steps
+        return attn_cluster_bwd_reduce(p, dkeys, dmem, dvpart, st);
+    TACO_RETURN_LAST();
+}
+
+int attn_cluster_bwd_reduce(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st) {
+    hipLaunchKernelGGL(attn_hoisted_bwd_k, dim3((p.Ti + HT - 1) / HT, p.N), dim3(256), 0, st, p.keys, p.q, p.align, p.de, p.dctx, p.v,
+                       dkeys, dmem, dvpart, p.S, p.Ti);
     TACO_RETURN_LAST();
 }

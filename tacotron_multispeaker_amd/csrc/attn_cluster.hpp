@@ -23,3 +23,4 @@ struct AttnCluB {
     u64* carry_xchg;                 // exchange buffer whose carry region / residency counter is used (the POSTING launch's buffer)
 };
 int attn_cluster_bwd_launch(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st);
+int attn_cluster_bwd_reduce(const AttnCluB& p, float* dkeys, float* dmem, float* dvpart, hipStream_t st);

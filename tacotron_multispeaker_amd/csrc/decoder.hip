@@ -504,8 +504,22 @@ extern "C" int taco_attn_rnn_bwd(const void* const* ptrs, const int* dims, hipSt
     return taco_attn_rnn_bwd_chunk(ptrs, dims, 0, nullptr, st);
 }
 
+// the reduction over the steps on its own (after a TACO_ATTN_NO_REDUCE launch, once the streams of all chunks are joined)
+extern "C" int taco_attn_bwd_reduce(const void* const* ptrs, const int* dims, hipStream_t st) {
+    if (!ptrs || !dims) return TACO_EINVAL;
+    const int N = dims[0], S = dims[1], Ti = dims[2];
+    if (N <= 0 || S <= 0 || Ti <= 0 || !ptrs[TACO_AP_DE] || !ptrs[TACO_AP_DCTXS] || !taco_attn_cluster_supported(N, Ti)) return TACO_EINVAL;
+    AttnCluB p{};
+    p.keys = (const float*)ptrs[TACO_AP_KEYS]; p.q = (const float*)ptrs[TACO_AP_Q]; p.align = (const float*)ptrs[TACO_AP_ALIGN];
+    p.v = (const float*)ptrs[TACO_AP_V];
+    p.de = (float*)const_cast<void*>(ptrs[TACO_AP_DE]); p.dctx = (float*)const_cast<void*>(ptrs[TACO_AP_DCTXS]);
+    p.N = N; p.S = S; p.Ti = Ti;
+    return attn_cluster_bwd_reduce(p, (float*)const_cast<void*>(ptrs[TACO_AP_DKEYS]), (float*)const_cast<void*>(ptrs[TACO_AP_DMEM]),
+                                   (float*)const_cast<void*>(ptrs[TACO_AP_DVPART]), st);
+}
+
 extern "C" int taco_attn_rnn_bwd_chunk(const void* const* ptrs, const int* dims, int carry_flags, void* carry_xchg, hipStream_t st) {
-    if (!ptrs || !dims || (carry_flags & ~3)) return TACO_EINVAL;
+    if (!ptrs || !dims || (carry_flags & ~7)) return TACO_EINVAL;
     const int N = dims[0], S = dims[1], Ti = dims[2];
     if (N <= 0 || S <= 0 || Ti <= 0) return TACO_EINVAL;
     if (ptrs[TACO_AP_XCHG] && ptrs[TACO_AP_ERR] && ptrs[TACO_AP_DE] && ptrs[TACO_AP_DCTXS] && taco_attn_cluster_supported(N, Ti)) {
@@ -528,7 +542,7 @@ extern "C" int taco_attn_rnn_bwd_chunk(const void* const* ptrs, const int* dims,
         if ((carry_flags & TACO_ATTN_CARRY_POST) && p.s0 == 0) return TACO_EINVAL;      // the last one hands none over
         return attn_cluster_bwd_launch(p, G(TACO_AP_DKEYS), G(TACO_AP_DMEM), G(TACO_AP_DVPART), st);
     }
-    if (carry_flags) return TACO_EINVAL;                 // the per-step kernels run a pass in one call
+    if (carry_flags) return TACO_EINVAL;                 // the per-step kernels run a pass in one call, reduction included
     if (dims[3] != 0 || dims[4] != S) return TACO_EINVAL;
     return attn_rnn_bwd_steps(ptrs, dims, st);
 }

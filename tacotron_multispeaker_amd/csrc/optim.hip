@@ -164,11 +164,12 @@ extern "C" int taco_spin_us(int us, hipStream_t stream) {
 }
 
 // One wave that returns once *counter >= target: puts work of its stream behind something only a RUNNING kernel can signal (the
-// residency counter of taco_attn_rnn_bwd_chunk).  Bounded by the wall clock (~50 ms), then the error word is set.
+// residency counter of taco_attn_rnn_bwd_chunk).  Bounded by the wall clock (~0.5 s at 100 MHz), then the error word is set; the caller
+// enqueues it only AFTER it has issued the launch that signals the counter, so the wait is device time, never host time.
 __global__ void wait_count_k(const int* __restrict__ counter, int target, int* err) {
     const long t0 = wall_clock64();
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (wall_clock64() - t0 > 5000000L) { if (err) atomicExch(err, 4); break; }      // (4: told apart from a hand-off timeout in logs; any non-zero word invalidates the step)
+        if (wall_clock64() - t0 > 50000000L) { if (err) atomicExch(err, 4); break; }      // (4: told apart from a hand-off timeout in logs; any non-zero word invalidates the step)
         __builtin_amdgcn_s_sleep(16);
     }
 }

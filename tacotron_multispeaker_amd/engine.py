@@ -1271,7 +1271,7 @@ class Engine:
                 tab2 = (ctypes.c_void_p * len(_AP))(*list(tab))         # the same tensors, an exchange buffer of its own
                 tab2[AP['XCHG']] = xchg2.data_ptr()
                 self._timed('attention recurrence bwd (attn_cluster_bwd_k)', 2 * self._attn_flops(nb, Ti, s1 - s0),
-                            lambda: lib.taco_attn_rnn_bwd_chunk(tab2, self._dims(nb, S, Ti, s0, s1), 2, self._attn_keep['XCHG'], self.st))
+                            lambda: lib.taco_attn_rnn_bwd_chunk(tab2, self._dims(nb, S, Ti, s0, s1), 2 | 4, self._attn_keep['XCHG'], self.st))
             else:
                 sc_.wait_event(ev2)
                 with torch.cuda.stream(sc_):
@@ -1300,7 +1300,11 @@ class Engine:
                     # small projection GEMMs that gate the attention chunks, so those are launched back to back and the flood never
                     # finds the attention CUs empty), attn = behind the launch point of the last attention chunk's predecessor
                     after = os.environ.get('TACO_FLUSH_AFTER', 'gru1')
-                    if early and self._side_active:
+                    if early and self._side_active and ci == len(chunks) - 1:
+                        # (only when the launch the gate waits for has already been ISSUED, above: a gate enqueued earlier --
+                        # TACO_FLUSH_AT < last chunk -- would spin while the host is still on its way to that launch, and a first
+                        # step's one-off host stalls, module loads and allocations, exceed any sensible bound: seen once as a
+                        # timeout of the 50 ms gate in the TACO_FLUSH_AT=0 test)
                         dll = lib.load()
                         ctr = self._attn_keep['XCHG'].data_ptr() + 8 * dll.taco_attn_bwd_resident_slot(min(N, self.ATTN_ROWS), Ti)
                         wgs = dll.taco_attn_bwd_workgroups(min(N, self.ATTN_ROWS))
@@ -1308,6 +1312,11 @@ class Engine:
                     self.flush_side(ready=ev2 if (after == 'gru1' and len(chunks) > 1) else None)
         if len(chunks) > 1:
             cur.wait_stream(sb); cur.wait_stream(sc_)
+        if early:
+            # the reduction over the steps reads what EVERY chunk stored: the early-resident launch above ends once its predecessor has
+            # published the carries, which does not order that predecessor's last stores (other stream, kernel possibly not yet retired)
+            nb, tab = self._attn_ptrs[0]
+            lib.taco_attn_bwd_reduce(tab, self._dims(nb, S, Ti, 0, S), self.st)
         self._mark('decoder bwd')
         dY = dD
         # weight gradients of the decoder (deferred to the side stream)
