@@ -868,15 +868,25 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
     __shared__ __attribute__((aligned(16))) float smem[STAGES][SSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int c0 = bx * BM, n0 = by * BN;
+    const int n0 = by * BN;
     // bz = split * nseg + segment: the (conv width, tap) segments of one row range are neighbours in the tile order, so the row
     // range's X and dY tiles are re-read from L2 for every tap instead of from memory (conv bank: sum k = 36 / 136 taps)
-    const int nseg = p.bank ? p.kw_hi * (p.kw_hi + 1) / 2 : p.kw_lo;
+    // bank == 2 ("flat" bank, Cin not a multiple of BM -- the post-net's 80 mel channels): the X-column tiles of one conv width walk the
+    // FLATTENED (tap, channel) rows of that width's kernel, kw * Cin of them, instead of cdiv(Cin, BM) tiles per tap: a tile then holds
+    // channels of up to two neighbouring taps (each lane group of 4 channels carries its own row shift), and the 136 taps of a K = 16
+    // bank over 80 channels take 176 tiles instead of 272 (the second tile of every tap was 3/4 padding).
+    const bool flat = p.bank == 2;
+    int nseg = p.bank ? p.kw_hi * (p.kw_hi + 1) / 2 : p.kw_lo;
+    if (flat) { nseg = 0; for (int k = 1; k <= p.kw_hi; ++k) nseg += (k * p.K + BM - 1) / BM; }
     const int split = bz / nseg;
     int seg = bz - split * nseg;
     int kw = p.kw_lo, j = seg;
-    if (p.bank) { kw = 1; while (seg >= kw) { seg -= kw; ++kw; } j = seg; }
-    const int shift = j - (kw - 1) / 2 + p.shift0;
+    if (flat) { kw = 1; while (seg >= (kw * p.K + BM - 1) / BM) { seg -= (kw * p.K + BM - 1) / BM; ++kw; } j = 0; }
+    else if (p.bank) { kw = 1; while (seg >= kw) { seg -= kw; ++kw; } j = seg; }
+    const int c0 = flat ? seg * BM : bx * BM;                // first output row of this tile: flat (tap, channel) index / channel
+    const int klim = flat ? kw * p.K : p.K;                  // rows of this output block
+    const int shift = (flat ? c0 / p.K : j) - (kw - 1) / 2 + p.shift0;                 // row shift of the tile's first tap ...
+    const int shift_hi = flat ? shift + (min(c0 + BM, klim) - 1) / p.K - c0 / p.K : shift;     // ... and of its last one
     const int aoff = p.bank ? (kw - 1) * p.cpb : 0;
     const int ldc = p.bank ? p.cpb : p.ldc;
     float* Cw = p.C + (p.bank ? (long)p.K * p.cpb * ((kw - 1) * kw / 2) : 0) + (long)j * p.K * ldc;
@@ -891,11 +901,13 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
 
     int mla[NVA], mlb[NVB];
     unsigned voa_in[NVA], vob_in[NVB];
+    const int cl = c0 + (lane % LPRA) * 4;                   // this lane's 4 output rows (Cin % 4 == 0: one tap)
+    const int jl = flat ? cl / p.K - c0 / p.K : 0;           // its tap, relative to the tile's first
+    const int ccl = flat ? cl - (cl / p.K) * p.K : cl;       // its channel
 #pragma unroll
     for (int v = 0; v < NVA; ++v) {
         mla[v] = (v * 4 + wave) * RA + lane / LPRA;
-        const int c = c0 + (lane % LPRA) * 4;
-        voa_in[v] = c < p.K ? (unsigned)(mla[v] * p.lda + c) * 4u : TACO_OOB;
+        voa_in[v] = cl < klim ? (unsigned)((mla[v] + jl) * p.lda + ccl) * 4u : TACO_OOB;
     }
 #pragma unroll
     for (int v = 0; v < NVB; ++v) {
@@ -910,7 +922,7 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
     auto issue = [&](float* stage) {
         const int mbase = i_kt * BK;
         const bool full = mbase + BK <= p.M;
-        const bool interior = full && (shift == 0 || (t0 + shift >= 0 && t0 + BK - 1 + shift < p.T && t0 + BK - 1 < p.T));
+        const bool interior = full && ((shift == 0 && shift_hi == 0) || (t0 + shift >= 0 && t0 + BK - 1 + shift_hi < p.T && t0 + BK - 1 < p.T));
         if (interior) {
 #pragma unroll
             for (int v = 0; v < NVA; ++v) buf_load_lds16(Ab, stage + (v * 4 + wave) * RA * BM, voa_in[v], soa);
@@ -918,7 +930,7 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
 #pragma unroll
             for (int v = 0; v < NVA; ++v) {
                 const int m = mbase + mla[v];
-                const bool ok = m < p.M && (unsigned)(m % p.T + shift) < (unsigned)p.T;
+                const bool ok = m < p.M && (unsigned)(m % p.T + shift + jl) < (unsigned)p.T;
                 buf_load_lds16(Ab, stage + (v * 4 + wave) * RA * BM, ok ? voa_in[v] : TACO_OOB, soa);
             }
         }
@@ -993,7 +1005,7 @@ __device__ __forceinline__ void tn2_body(const ConvGemm& p, const int bx, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = c0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < p.K) atomicAdd(Cw + (long)row * ldc + col, acc[mi][ni][r]);
+                if (row < klim) atomicAdd(Cw + (long)row * ldc + col, acc[mi][ni][r]);
             }
     }
 }
@@ -1306,6 +1318,19 @@ static int plan_bwd_weight(ConvGemm& p, dim3& g, int& cfg, const float* X, const
     const bool v2 = !force_v1 && ((long)M + 64) * ldx * 4 < (1L << 31) && ((long)M + 64) * lddy * 4 < (1L << 31);
     cfg = !v2 ? (big ? 4 : 3) : big ? 2 : (cdiv(ktiles, splitk) <= 8 ? 1 : 0);
     p.dbias = (cfg <= 1 && kw == 1 && bank_K == 0) ? dbias : nullptr;      // fused bias gradient: dense problems on the 64x64x32 v2 kernel
+    // flat bank (tn2_body): the X-column tiles walk the (tap, channel) rows of a conv width without per-tap padding.  TACO_BANK_FLAT=0: off
+    static const int bank_flat = env_int("TACO_BANK_FLAT", 1);
+    if (bank_K > 0 && cfg <= 1 && bank_flat && p.K % bm != 0) {
+        int segs = 0;
+        for (int k = 1; k <= bank_K; ++k) segs += cdiv(k * p.K, bm);
+        // (the split was planned on the padded tile count: re-plan it on the real one)
+        splitk = (int)((wgs_target + (long)segs * cdiv(p.N, bm) - 1) / ((long)segs * cdiv(p.N, bm)));
+        if (splitk > max_split) splitk = max_split;
+        if (splitk < 1) splitk = 1;
+        p.bank = 2; p.splitk = splitk;
+        g = dim3(1, cdiv(p.N, bm), segs * splitk);
+        cfg = cdiv(ktiles, splitk) <= 8 ? 1 : 0;
+    }
     return TACO_OK;
 }
 

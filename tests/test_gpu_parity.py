@@ -417,7 +417,11 @@ def test_conv_gemm_forward_backward(M, T, cin, cout, kw):
     assert float(dw[:, :, cout:].abs().max()) == 0 if ldw > cout else True
 
 
-@pytest.mark.parametrize('N,T,cin,K', [(3, 20, 128, 16), (2, 35, 80, 8), (32, 128, 128, 16)])
+@pytest.mark.parametrize('N,T,cin,K', [(3, 20, 128, 16), (2, 35, 80, 8), (32, 128, 128, 16),
+                                       # weight gradient over the flattened (tap, channel) rows (Cin not a multiple of the 64-row tile: a tile
+                                       # holds channels of two or more taps, each with its own row shift): post-net shape, sequences shorter
+                                       # than a 32-row reduction tile, Cin < 64 (three taps in a tile), several reduction splits
+                                       (4, 100, 80, 16), (9, 24, 40, 5), (2, 70, 96, 4), (16, 160, 80, 16)])
 def test_conv_bank(N, T, cin, K):
     from tacotron_multispeaker_amd._lib import lib, stream
     dev, M, C = 'cuda', N * T, K * 128
