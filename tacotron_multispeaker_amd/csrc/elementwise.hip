@@ -415,6 +415,82 @@ __global__ __launch_bounds__(256) void l1_loss_k(const float* __restrict__ out, 
     }
 }
 
+// Wide rows (the linear spectrogram: 1025 columns in rows of 1028): ONE WAVE PER ROW.  The flat form above spends an integer division per
+// element and keeps 4 elements per lane in flight -- 8 MB across the chip, less than the memory system needs to stream (85 us for 252 MB).
+// Here a lane owns float4 columns lane, lane + 64, ... of its row: the gradient moves as 16-byte stores (its rows are 16-byte aligned),
+// prediction and target -- rows of C = 1025 floats, not aligned -- as four dword loads each that the memory pipeline merges per cache
+// line; all loads of a row are issued before the first use.  Needs ldg % 4 == 0, a 16-byte aligned grad, ldg <= 4 * 64 * L1_NV.
+#define L1_NV 5
+__global__ __launch_bounds__(256) void l1_loss_wide_k(const float* __restrict__ out, int ldo, const float* __restrict__ tgt, int ldt,
+                                                     float* __restrict__ grad, int ldg, double* __restrict__ sums, int rows, int C,
+                                                     int npri, float w_all, float w_pri, int rb_len, int rb_stride, int rb_off) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s_all = 0.f, s_pri = 0.f;
+    const int nv = (ldg / 4 + 63) / 64;
+    for (int rl = blockIdx.x * 4 + wave; rl < rows; rl += gridDim.x * 4) {
+        const long r = rb_len ? (long)(rl / rb_len) * rb_stride + rb_off + rl % rb_len : (long)rl;
+        const float* o = out + r * ldo;
+        const float* t = tgt + r * ldt;
+        float ov[L1_NV][4], tv[L1_NV][4];
+#pragma unroll
+        for (int v = 0; v < L1_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (v < nv && c < ldg) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ov[v][k] = c + k < C ? o[c + k] : 0.f;
+                    tv[v][k] = c + k < C ? t[c + k] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < L1_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (v < nv && c < ldg) {
+                float g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    g[k] = 0.f;
+                    if (c + k < C) {
+                        const float d = ov[v][k] - tv[v][k];
+                        const float a = fabsf(d);
+                        s_all += a;
+                        float w = w_all;
+                        if (c + k < npri) { s_pri += a; w += w_pri; }
+                        g[k] = d > 0.f ? w : (d < 0.f ? -w : 0.f);
+                    }
+                }
+                *reinterpret_cast<float4*>(grad + r * ldg + c) = make_float4(g[0], g[1], g[2], g[3]);
+            }
+        }
+    }
+    const double a = wave_sum_d((double)s_all), b = wave_sum_d((double)s_pri);
+    __shared__ double red[2][4];
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* sr = sums + 2 * (blockIdx.x % TACO_L1_REPL);
+        atomicAdd(sr, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(sr + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+static void l1_launch(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2, long rows, int C, int npri,
+                      float w_all, float w_pri, int rb_len, int rb_stride, int rb_off, hipStream_t stream) {
+    static const int no_wide = getenv("TACO_L1_WIDE") && atoi(getenv("TACO_L1_WIDE")) == 0;
+    const bool wide = !no_wide && grad && C >= 256 && ldg <= 4 * 64 * L1_NV && !(ldg & 3) && !(reinterpret_cast<uintptr_t>(grad) & 15) &&
+                      rows < (1L << 31);
+    if (wide) {
+        const long blocks = (rows + 3) / 4;
+        hipLaunchKernelGGL(l1_loss_wide_k, dim3((int)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2,
+                           (int)rows, C, npri, w_all, w_pri, rb_len, rb_stride, rb_off);
+        return;
+    }
+    const long blocks = (rows * ldg + 1023) / 1024;
+    hipLaunchKernelGGL(l1_loss_k, dim3((int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2,
+                       rows, C, npri, w_all, w_pri, rb_len, rb_stride, rb_off);
+}
+
 // =====================================================================================================
 // C-ABI wrappers
 // =====================================================================================================
@@ -702,8 +778,7 @@ extern "C" int taco_align_regularity(const float* align, float* dalign, double* 
 extern "C" int taco_l1_loss(const float* out, int ldo, const float* tgt, int ldt, float* grad, int ldg, double* sums2,
                             long rows, int C, int npri, float w_all, float w_pri, hipStream_t stream) {
     if (!out || !tgt || !sums2 || ldg < C || (ldg & 3) || rows * ldg >= (1L << 31)) return TACO_EINVAL;
-    const long blocks = (rows * ldg + 1023) / 1024;
-    hipLaunchKernelGGL(l1_loss_k, dim3((int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri, 0, 0, 0);
+    l1_launch(out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri, 0, 0, 0, stream);
     TACO_RETURN_LAST();
 }
 
@@ -712,7 +787,6 @@ extern "C" int taco_l1_loss_rows(const float* out, int ldo, const float* tgt, in
     if (!out || !tgt || !sums2 || ldg < C || (ldg & 3) || N <= 0 || T <= 0 || f0 < 0 || f1 > T || f0 >= f1) return TACO_EINVAL;
     if ((long)N * T * ldg >= (1L << 31)) return TACO_EINVAL;
     const long rows = (long)N * (f1 - f0);
-    const long blocks = (rows * ldg + 1023) / 1024;
-    hipLaunchKernelGGL(l1_loss_k, dim3((int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri, f1 - f0, T, f0);
+    l1_launch(out, ldo, tgt, ldt, grad, ldg, sums2, rows, C, npri, w_all, w_pri, f1 - f0, T, f0, stream);
     TACO_RETURN_LAST();
 }

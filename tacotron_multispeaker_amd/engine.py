@@ -431,9 +431,11 @@ class Engine:
                     self._emit(run)
                 self._side_rr += 1
                 del run[:]
+        drop = os.environ.get('TACO_DEV_DROP_WGRAD') == '1'       # developer bound: the step WITHOUT its deferred weight gradients (wrong results)
         for fn in self._deferred:
             if isinstance(fn, tuple) and fn[0] in ('dw', 'cs'):
-                run.append(fn)
+                if not drop:
+                    run.append(fn)
                 continue
             emit_run()
             if isinstance(fn, tuple):      # ('bucket', go): every producer of a gradient bucket is now enqueued
