@@ -49,7 +49,43 @@ for name, M, T, cin, cout, kw, bank in shapes:
     mx = float((dx.double() - ref).abs().max() / ref.abs().max())
     fl = 2.0 * M * taps * cin * (128 if bank else cout)
     t = timeit(f)
-    print('%%-12s X3=%%s  rel-norm err %%.2e  max-abs/max %%.2e   %%7.1f us %%6.1f TF(fp32-equivalent)' %% (name, os.environ.get('TACO_X3', '1'), err, mx, t, fl / t / 1e6), flush=True)
+    print('%%-12s X3=%%s  dX  rel-norm err %%.2e  max-abs/max %%.2e   %%7.1f us %%6.1f TF(fp32-equivalent)' %% (name, os.environ.get('TACO_X3', '1'), err, mx, t, fl / t / 1e6), flush=True)
+    # forward: y = relu(conv(x, w) + b)
+    x = torch.randn(M, cin, device=dev); b = torch.randn(max(ldw, cout) if not bank else cout, device=dev)
+    y = torch.empty(M, cout, device=dev)
+    g = lambda: lib.taco_conv_gemm_fwd(x, w, b, y, M, T, cin, cout, kw, bank, cin, ldw, cout, 1, 0, stream())
+    g(); torch.cuda.synchronize()
+    x64 = x.double()
+    outs = []
+    k0 = 0
+    for k in (range(1, kw + 1) if bank else [kw]):
+        wk = w64[k0:k0 + k, :, :128 if bank else cout]; k0 += k
+        outs.append(conv_ref(x64, wk, T))
+    ref = torch.relu(torch.cat(outs, 1) + b[:cout].double())
+    err = float((y.double() - ref).norm() / ref.norm())
+    mx = float((y.double() - ref).abs().max() / ref.abs().max())
+    t = timeit(g)
+    # weight gradient: dW_j = sum_m X[m + j - pl]^T dY[m]
+    dw = torch.zeros_like(w)
+    hfn = lambda: lib.taco_conv_gemm_bwd_weight(x, dy, dw, M, T, cin, cout, kw, bank, cin, lddy, ldw, stream())
+    hfn(); torch.cuda.synchronize()
+    refw = torch.zeros(taps, cin, 128 if bank else cout, dtype=torch.float64, device=dev)
+    k0 = 0
+    for k in (range(1, kw + 1) if bank else [kw]):
+        g64 = d64[:, (k - 1) * 128:k * 128] if bank else d64[:, :cout]
+        pl = (k - 1) // 2
+        xp = torch.nn.functional.pad(x64.view(N, T, cin), (0, 0, pl, k // 2))
+        for j in range(k):
+            refw[k0 + j] = xp[:, j:j + T, :].reshape(M, cin).t() @ g64
+        k0 += k
+    got = dw[:, :, :128 if bank else cout].double()
+    errw = float((got - refw).norm() / refw.norm())
+    mxw = float((got - refw).abs().max() / refw.abs().max())
+    def hrun():
+        dw.zero_(); hfn()
+    tw = timeit(hfn)
+    print('%%-12s X3=%%s  dW  rel-norm err %%.2e  max-abs/max %%.2e   %%7.1f us %%6.1f TF(fp32-equivalent)' %% (name, os.environ.get('TACO_X3', '1'), errw, mxw, tw, fl / tw / 1e6), flush=True)
+    print('%%-12s X3=%%s  fwd rel-norm err %%.2e  max-abs/max %%.2e   %%7.1f us %%6.1f TF(fp32-equivalent)' %% (name, os.environ.get('TACO_X3', '1'), err, mx, t, fl / t / 1e6), flush=True)
 ''' % ROOT
-for x3 in ('0', '1'):
+for x3 in ('0', '2'):
     subprocess.run([sys.executable, '-c', CHILD], env=dict(os.environ, TACO_X3=x3), check=False)

@@ -918,6 +918,167 @@ __global__ __launch_bounds__(256) void conv_gemm_nt3(ConvGemm p) {
 }
 
 // =====================================================================================================
+// NN v3 (forward of the large conv / dense layers), bf16x3 products like conv_gemm_nt3.  The weights W[j][k][n] are k-strided: a
+// fragment needs 8 consecutive k of one column n, so the B tile is fetched column-wise -- a thread owns column tid % 128 and the
+// k quads tid / 128 + 2 v, sixteen dword loads whose lanes cover 256 contiguous bytes of a weight row -- and its four k values are
+// packed in k order: no transposition in registers or LDS.  Both LDS images are [row or column][32 k] bf16 with rows padded to 80
+// bytes: the fragment reads (32 consecutive rows, one 16-byte chunk) and the 8-byte tile writes of consecutive rows are conflict-free
+// without a swizzle.  One conv width per 128-column tile (bank: cpb = 128).
+// =====================================================================================================
+template <bool KTAIL>
+__global__ __launch_bounds__(256) void conv_gemm_nn3(ConvGemm p) {
+    constexpr int BM = 128, BN = 128, BK = 32, RS = 80;    // RS: bytes per LDS row (64 + 16 pad)
+    constexpr int PLANE = BM * RS;                         // one bf16 plane of one operand (10 KiB)
+    constexpr int STAGE = 4 * PLANE;                       // A hi, A lo, B hi, B lo
+    constexpr int NV = BM / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.bank) by = gridDim.y - 1 - blockIdx.y;                         // bank: widest convs first
+    else xcd_tile(bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
+    int kw = p.kw_lo, ldb = p.ldb, nloc0 = n0, nlim = p.N;
+    const float* Bb = p.B;
+    if (p.bank) {
+        kw = 1 + n0 / p.cpb;
+        Bb = p.B + (long)p.K * p.cpb * ((kw - 1) * kw / 2);
+        ldb = p.cpb;
+        nloc0 = n0 - (kw - 1) * p.cpb;
+        nlim = p.cpb;
+    }
+    const int pl = (kw - 1) / 2;
+    const int ksteps = (p.K + BK - 1) / BK;
+    const int total = kw * ksteps;
+    const int per = (total + p.splitk - 1) / p.splitk;
+    const int s_begin = blockIdx.z * per;
+    const int nsteps = min(total, s_begin + per) - s_begin;
+    if (nsteps <= 0) return;
+
+    const int rl = tid >> 3, ck = tid & 7;                 // A: rows rl + 32 v, 4-float chunk ck
+    int tpos[NV];
+    unsigned arow[NV];
+    bool arok[NV];
+    const int klast = (ksteps - 1) * BK;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int r = rl + 32 * v;
+        tpos[v] = seqpos(p, m0 + r);
+        arow[v] = (unsigned)rowmap(p, m0 + r);
+        arok[v] = m0 + r < p.M;
+    }
+    const int bn = tid & 127, bq = tid >> 7;               // B: column bn, k quads bq + 2 v
+    const unsigned vob_col = nloc0 + bn < nlim ? (unsigned)(nloc0 + bn) * 4u : TACO_OOB;
+    unsigned voa[NV], voa_last[NV];
+    auto tap_offsets = [&](int j) {
+        const int shift = j - pl;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool ok = arok[v] && (unsigned)(tpos[v] + shift) < (unsigned)p.T;
+            voa[v] = ok ? ((arow[v] + shift) * (unsigned)p.lda + ck * 4) * 4u : TACO_OOB;
+            voa_last[v] = klast + ck * 4 < p.K ? voa[v] : TACO_OOB;
+        }
+    };
+    const int bstep = BK * ldb * 4, btap = p.K * ldb * 4;
+    int i_j = s_begin / ksteps, i_kc = s_begin - i_j * ksteps, issued = 0;
+    int soa = i_kc * BK * 4, sob = __builtin_amdgcn_readfirstlane(i_j * btap + i_kc * bstep);
+    bool need_tap = true;
+    u32x4_t ra[NV];
+    float rb[NV][4];
+    auto load = [&]() {
+        if (need_tap) { tap_offsets(i_j); need_tap = false; }
+        const bool last = KTAIL && i_kc == ksteps - 1;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) ra[v] = buf_load16(p.A, last ? voa_last[v] : voa[v], soa);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kl = (bq + 2 * v) * 4 + i;
+                const bool ok = !KTAIL || !last || klast + kl < p.K;
+                rb[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? vob_col + (unsigned)(kl * ldb) * 4u : TACO_OOB, sob, 0));
+            }
+        ++i_kc; ++issued; soa += BK * 4; sob += bstep;
+        if (i_kc == ksteps) { i_kc = 0; ++i_j; soa = 0; sob = __builtin_amdgcn_readfirstlane(i_j * btap); need_tap = true; }
+    };
+    auto stage_write = [&](unsigned char* st) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            uint2 hi, lo;
+            split_bf16x2(ra[v], hi, lo);
+            const int wa = (rl + 32 * v) * RS + ck * 8;
+            *reinterpret_cast<uint2*>(st + wa) = hi;
+            *reinterpret_cast<uint2*>(st + PLANE + wa) = lo;
+            const u32x4_t bv = {__float_as_uint(rb[v][0]), __float_as_uint(rb[v][1]), __float_as_uint(rb[v][2]), __float_as_uint(rb[v][3])};
+            split_bf16x2(bv, hi, lo);
+            const int wb = bn * RS + (bq + 2 * v) * 8;
+            *reinterpret_cast<uint2*>(st + 2 * PLANE + wb) = hi;
+            *reinterpret_cast<uint2*>(st + 3 * PLANE + wb) = lo;
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    int fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            fa[i][kk] = (wm * 64 + i * 32 + fr) * RS + (2 * kk + fh) * 16;
+            fb[i][kk] = (wn * 64 + i * 32 + fr) * RS + (2 * kk + fh) * 16;
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    auto mma = [&](const unsigned char* st) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(st + fa[i][kk]);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(st + PLANE + fa[i][kk]);
+                bh[i] = *reinterpret_cast<const bf16x8_t*>(st + 2 * PLANE + fb[i][kk]);
+                bl[i] = *reinterpret_cast<const bf16x8_t*>(st + 3 * PLANE + fb[i][kk]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+    };
+    load();
+    for (int t = 0; t < nsteps; ++t) {
+        unsigned char* st = smem + (t & 1) * STAGE;
+        stage_write(st);
+        __syncthreads();
+        if (issued < nsteps) load();
+        mma(st);
+    }
+    if (p.splitk == 1) { epilogue_store<BM, BN>(p, acc, m0, n0, wm, wn, lane); return; }
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn * 64 + ni * 32 + i;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.M) atomicAdd(p.C + rowmap(p, row) * p.ldc + col, acc[mi][ni][r]);
+            }
+    }
+}
+
+// =====================================================================================================
 // TN: dW_kw[j][c][n] += sum_m X[m + j - pl, c] * dY[m, aoff(kw) + n]                     (weight gradient)
 //     p.M = reduction rows, p.K = Cin (output rows), p.N = Cout per conv (output cols);
 //     grid.z = segment(kw,j) * splitk + split; partial sums are atomically added into pre-zeroed C.
@@ -1195,6 +1356,168 @@ __global__ __launch_bounds__(256) void conv_gemm_tn2(ConvGemm p) {
     tn2_body<BM, BN, BK, STAGES>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// =====================================================================================================
+// TN v3 (weight gradients of the large layers), bf16x3 products like conv_gemm_nt3 / nn3.  Both operands are k-strided here (the
+// reduction runs over the ROWS of X and dY), so both tiles are fetched column-wise like the weights of conv_gemm_nn3: a thread owns
+// one X channel / dY column (tid % 128) and the row quads tid / 128 + 2 v of a 32-row reduction tile, packs its four rows in order
+// and writes 8 bytes of the [column][32 rows] bf16 image (80-byte rows).  Interior row tiles use loop-invariant lane offsets and a
+// scalar row walk like tn2; edge tiles (sequence ends under a tap shift, ragged M) compute their row masks.  128 x 128 output tiles,
+// split over the rows; partial sums are atomically added.  Flat bank rows (bank == 2) as in tn2_body: the tap is a per-thread constant.
+// =====================================================================================================
+__device__ __forceinline__ void tn3_body(const ConvGemm& p, const int bx, const int by, const int bz, unsigned char* smem) {
+    constexpr int BM = 128, BN = 128, BK = 32, RS = 80;
+    constexpr int PLANE = BM * RS, STAGE = 4 * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = by * BN;
+    const bool flat = p.bank == 2;
+    int nseg = p.bank ? p.kw_hi * (p.kw_hi + 1) / 2 : p.kw_lo;
+    if (flat) { nseg = 0; for (int k = 1; k <= p.kw_hi; ++k) nseg += (k * p.K + BM - 1) / BM; }
+    const int split = bz / nseg;
+    int seg = bz - split * nseg;
+    int kw = p.kw_lo, j = seg;
+    if (flat) { kw = 1; while (seg >= (kw * p.K + BM - 1) / BM) { seg -= (kw * p.K + BM - 1) / BM; ++kw; } j = 0; }
+    else if (p.bank) { kw = 1; while (seg >= kw) { seg -= kw; ++kw; } j = seg; }
+    const int c0 = flat ? seg * BM : bx * BM;
+    const int klim = flat ? kw * p.K : p.K;
+    const int shift = (flat ? c0 / p.K : j) - (kw - 1) / 2 + p.shift0;
+    const int shift_hi = flat ? shift + (min(c0 + BM, klim) - 1) / p.K - c0 / p.K : shift;
+    const int aoff = p.bank ? (kw - 1) * p.cpb : 0;
+    const int ldc = p.bank ? p.cpb : p.ldc;
+    float* Cw = p.C + (p.bank ? (long)p.K * p.cpb * ((kw - 1) * kw / 2) : 0) + (long)j * p.K * ldc;
+
+    const int ktiles = (p.M + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt0 = split * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+    const int nsteps = kt1 - kt0;
+    const float* Ab = p.A + (long)shift * p.lda;             // row m of this view is X[m + shift]
+    const float* Bbase = p.B + aoff;
+
+    const int col = tid & 127, q0 = tid >> 7;                // this thread's column of both tiles, row quads q0 + 2 v
+    const int cl = c0 + col;
+    const int jl = flat ? cl / p.K - c0 / p.K : 0;
+    const int ccl = flat ? cl - (cl / p.K) * p.K : cl;
+    const unsigned voa = cl < klim ? (unsigned)(jl * p.lda + ccl) * 4u : TACO_OOB;
+    const unsigned vob = n0 + col < p.N ? (unsigned)(n0 + col) * 4u : TACO_OOB;
+    int i_kt = kt0, issued = 0;
+    int t0 = (kt0 * BK) % p.T;
+    const int astep = BK * p.lda * 4, bstep = BK * p.ldb * 4;
+    int soa = __builtin_amdgcn_readfirstlane(kt0 * astep), sob = __builtin_amdgcn_readfirstlane(kt0 * bstep);
+    float ra[4][4], rb[4][4];
+    auto load = [&]() {
+        const int mbase = i_kt * BK;
+        const bool full = mbase + BK <= p.M;
+        const bool interior = full && ((shift == 0 && shift_hi == 0) || (t0 + shift >= 0 && t0 + BK - 1 + shift_hi < p.T && t0 + BK - 1 < p.T));
+        const auto ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, 0x7FFFFFFF, 0x00020000);
+        const auto rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bbase), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = (q0 + 2 * v) * 4 + i;
+                unsigned oa = voa == TACO_OOB ? TACO_OOB : voa + (unsigned)(ml * p.lda) * 4u;
+                unsigned ob = vob == TACO_OOB ? TACO_OOB : vob + (unsigned)(ml * p.ldb) * 4u;
+                if (!interior) {
+                    const int m = mbase + ml;
+                    if (!(m < p.M && (unsigned)(m % p.T + shift + jl) < (unsigned)p.T)) oa = TACO_OOB;
+                    if (!(m < p.M)) ob = TACO_OOB;
+                }
+                ra[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra_rsrc, oa, soa, 0));
+                rb[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, ob, sob, 0));
+            }
+        ++i_kt; ++issued; soa += astep; sob += bstep;
+        t0 += BK; if (t0 >= p.T) t0 %= p.T;
+    };
+    auto stage_write = [&](unsigned char* st) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            uint2 hi, lo;
+            const int w = col * RS + (q0 + 2 * v) * 8;
+            const u32x4_t av = {__float_as_uint(ra[v][0]), __float_as_uint(ra[v][1]), __float_as_uint(ra[v][2]), __float_as_uint(ra[v][3])};
+            split_bf16x2(av, hi, lo);
+            *reinterpret_cast<uint2*>(st + w) = hi;
+            *reinterpret_cast<uint2*>(st + PLANE + w) = lo;
+            const u32x4_t bv = {__float_as_uint(rb[v][0]), __float_as_uint(rb[v][1]), __float_as_uint(rb[v][2]), __float_as_uint(rb[v][3])};
+            split_bf16x2(bv, hi, lo);
+            *reinterpret_cast<uint2*>(st + 2 * PLANE + w) = hi;
+            *reinterpret_cast<uint2*>(st + 3 * PLANE + w) = lo;
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    int fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            fa[i][kk] = (wm * 64 + i * 32 + fr) * RS + (2 * kk + fh) * 16;
+            fb[i][kk] = (wn * 64 + i * 32 + fr) * RS + (2 * kk + fh) * 16;
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    auto mma = [&](const unsigned char* st) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(st + fa[i][kk]);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(st + PLANE + fa[i][kk]);
+                bh[i] = *reinterpret_cast<const bf16x8_t*>(st + 2 * PLANE + fb[i][kk]);
+                bl[i] = *reinterpret_cast<const bf16x8_t*>(st + 3 * PLANE + fb[i][kk]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+    };
+    // bias gradient of a dense layer = column sums of dY: the workgroups of the first X-column tile add up the dY values they stage
+    // anyway (this thread: its column, 16 of the 32 rows of every tile; rows beyond M were loaded as zeros)
+    const bool do_bias = p.dbias != nullptr && bx == 0 && seg == 0;
+    float bsum = 0.f;
+    load();
+    for (int t = 0; t < nsteps; ++t) {
+        unsigned char* st = smem + (t & 1) * STAGE;
+        if (do_bias) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bsum += (rb[v][0] + rb[v][1]) + (rb[v][2] + rb[v][3]);
+        }
+        stage_write(st);
+        __syncthreads();
+        if (issued < nsteps) load();
+        mma(st);
+    }
+    if (do_bias && n0 + col < p.N) atomicAdd(p.dbias + n0 + col, bsum);
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int cn = n0 + wn * 64 + ni * 32 + i;
+        if (cn >= p.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < klim) atomicAdd(Cw + (long)row * ldc + cn, acc[mi][ni][r]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_gemm_tn3(ConvGemm p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * 128 * 80];
+    tn3_body(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
 // Grouped weight-gradient launch: ONE grid walks the tiles of up to TACO_WG_MAX independent dW problems (largest first).
 // Backward produces 44 weight-gradient GEMMs per step, most of them 10-40 us: launched one by one on the side stream their
 // launch gaps and ramp-up/drain phases are a third of the stream's time and every launch is a new burst of workgroups
@@ -1224,6 +1547,20 @@ __global__ __launch_bounds__(256) void conv_gemm_tn2_group(WgradGroup g) {
     for (int y = 0; y < x; ++y) base += upto(end, y) - upto(first, y);
     const int r = base + upto(b, x) - upto(first, x);
     tn2_body<BM, BN, BK, STAGES>(g.p[i], r % gx, (r / gx) % gy, r / (gx * gy));
+}
+
+__global__ __launch_bounds__(256) void conv_gemm_tn3_group(WgradGroup g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * 128 * 80];
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.count && b >= g.first[i + 1]) ++i;
+    const int first = g.first[i], end = g.first[i + 1], gx = g.gx[i], gy = g.gy[i];
+    auto upto = [](int n, int x) { return (n + 7 - x) >> 3; };       // same XCD-aware tile order as conv_gemm_tn2_group
+    const int x = b & 7;
+    int base = 0;
+    for (int y = 0; y < x; ++y) base += upto(end, y) - upto(first, y);
+    const int r = base + upto(b, x) - upto(first, x);
+    tn3_body(g.p[i], r % gx, (r / gx) % gy, r / (gx * gy), smem);
 }
 
 // ---- host-side dispatch --------------------------------------------------------------------------------
@@ -1273,6 +1610,10 @@ static bool fits31(const ConvGemm& p) {
     return abytes < (1L << 31) && bbytes < (1L << 31);
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// TACO_X3: which GEMMs multiply on the BF16 matrix pipe with three MFMAs per fp32 product (conv_gemm_nt3 / tn3 / nn3): 0 = none (exact
+// fp32 products everywhere), 1 = the backward pass (input and weight gradients; default), 2 = the forward pass too.  Read at every launch
+// (not cached: bench.py and the tests time / check both settings in one process).
+static int x3_mode() { return env_int("TACO_X3", 1); }
 
 #define NN2_LAUNCH(BM_, BN_, BK_, ST_) do { dim3 g2(cdiv(p.M, BM_), cdiv(p.N, BN_), p.splitk); \
         if (p.K % BK_) hipLaunchKernelGGL((conv_gemm_nn2<BM_, BN_, BK_, ST_, true>), g2, dim3(256), 0, stream, p); \
@@ -1305,6 +1646,19 @@ static int launch_nn(ConvGemm p, hipStream_t stream) {
             if (sk > 1 && hipMemset2DAsync(p.C, (size_t)p.ldc * sizeof(float), 0, (size_t)p.N * sizeof(float), p.M, stream) == hipSuccess)
                 p.splitk = sk;
         }
+    }
+    // bf16x3 products (conv_gemm_nn3) for the large problems, only on request (TACO_X3=2): the forward pass takes the ReLU / max-pool
+    // decisions, and products good to 2^-17 flip ~6x more near-ties against the float64 oracle than fp32 products do
+    static const int x3_min_tiles = env_int("TACO_X3_MIN_TILES", 256);
+    if (x3_mode() >= 2 && force_cfg < 0 && tiles128 * p.splitk >= x3_min_tiles && p.N >= 64 && (!p.bank || p.cpb == 128)) {
+        dim3 g3(cdiv(p.M, 128), cdiv(p.N, 128), p.splitk);
+        if (p.K % 32) hipLaunchKernelGGL((conv_gemm_nn3<true>), g3, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_nn3<false>), g3, dim3(256), 0, stream, p);
+        if (p.splitk > 1 && (p.bias || p.act != ACT_NONE)) {
+            const long work = (long)p.M * p.N;
+            hipLaunchKernelGGL(bias_act_k, dim3((int)((work + 1023) / 1024 > 2048 ? 2048 : (work + 1023) / 1024)), dim3(256), 0, stream, p);
+        }
+        return p.splitk;
     }
     int cfg = force_cfg;
     if (cfg < 0) {
@@ -1413,8 +1767,8 @@ static void launch_nt(const ConvGemm& p, hipStream_t stream) {
         return;
     }
     // bf16x3 products (conv_gemm_nt3) for the large problems: >= 256 tiles of 128 x 128.  TACO_X3=0: exact fp32 products everywhere
-    static const int x3 = env_int("TACO_X3", 1), x3_min_tiles = env_int("TACO_X3_MIN_TILES", 256);
-    if (x3 && force_cfg < 0 && (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk >= x3_min_tiles && p.N >= 64) {
+    static const int x3_min_tiles = env_int("TACO_X3_MIN_TILES", 256);
+    if (x3_mode() >= 1 && force_cfg < 0 && (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk >= x3_min_tiles && p.N >= 64) {
         dim3 g3(cdiv(p.M, 128), cdiv(p.N, 128), p.splitk);
         if (p.K % 32) hipLaunchKernelGGL((conv_gemm_nt3<true>), g3, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_nt3<false>), g3, dim3(256), 0, stream, p);
@@ -1474,6 +1828,7 @@ extern "C" int taco_conv_rows_bwd_data(const float* dY, const float* W, float* d
 
 // plans one weight-gradient problem: fills p and the launch grid; cfg: 0 = v2 64x64x32 (3 stages; the grouped kernel's
 // configuration), 1 = v2 64x64x32 2 stages (short loops), 2 = v2 128x128x16, 3 = v1 64, 4 = v1 128
+static inline int ktiles32_for(int M) { return (M + 31) / 32; }
 static int plan_bwd_weight(ConvGemm& p, dim3& g, int& cfg, const float* X, const float* dY, float* dW, int M, int T, int Cin,
                            int Cout, int kw, int bank_K, int ldx, int lddy, int ldw, int shift0, int wgs_target, float* dbias = nullptr) {
     // dW must be zero-initialised (or hold a running sum): partial sums are atomically ADDED.
@@ -1506,6 +1861,28 @@ static int plan_bwd_weight(ConvGemm& p, dim3& g, int& cfg, const float* X, const
     const bool v2 = !force_v1 && ((long)M + 64) * ldx * 4 < (1L << 31) && ((long)M + 64) * lddy * 4 < (1L << 31);
     cfg = !v2 ? (big ? 4 : 3) : big ? 2 : (cdiv(ktiles, splitk) <= 8 ? 1 : 0);
     p.dbias = (cfg <= 1 && kw == 1 && bank_K == 0) ? dbias : nullptr;      // fused bias gradient: dense problems on the 64x64x32 v2 kernel
+    // bf16x3 products (tn3_body, 128 x 128 x 32 tiles; cfg 5) for the large problems: >= 2 GFLOP, both output dimensions >= 64
+    static const int x3_min_mflop = env_int("TACO_X3_MIN_MFLOP", 2000);
+    if (x3_mode() >= 1 && v2 && tn_big < 0 && p.N >= 64 && (bank_K > 0 ? p.K * bank_K : p.K) >= 64 &&
+        2.0 * M * p.K * p.N * nseg >= 1e6 * x3_min_mflop) {
+        int segs = nseg;
+        p.bank = bank_K > 0 ? 1 : 0;
+        if (bank_K > 0 && p.K % 128 != 0) {
+            segs = 0;
+            for (int k = 1; k <= bank_K; ++k) segs += cdiv(k * p.K, 128);
+            p.bank = 2;
+        }
+        const long t3 = (long)(p.bank == 2 ? 1 : cdiv(p.K, 128)) * cdiv(p.N, 128) * segs;
+        int sk = (int)((wgs_target / 2 + t3 - 1) / t3);
+        const int ms = ktiles32_for(M) / 8 > 0 ? ktiles32_for(M) / 8 : 1;
+        if (sk > ms) sk = ms;
+        if (sk < 1) sk = 1;
+        p.splitk = sk;
+        g = dim3(p.bank == 2 ? 1 : cdiv(p.K, 128), cdiv(p.N, 128), segs * sk);
+        cfg = 5;
+        p.dbias = (kw == 1 && bank_K == 0) ? dbias : nullptr;
+        return TACO_OK;
+    }
     // flat bank (tn2_body): the X-column tiles walk the (tap, channel) rows of a conv width without per-tap padding.  TACO_BANK_FLAT=0: off
     static const int bank_flat = env_int("TACO_BANK_FLAT", 1);
     if (bank_K > 0 && cfg <= 1 && bank_flat && p.K % bm != 0) {
@@ -1524,6 +1901,7 @@ static int plan_bwd_weight(ConvGemm& p, dim3& g, int& cfg, const float* X, const
 
 static void launch_bwd_weight(const ConvGemm& p, dim3 g, int cfg, hipStream_t stream) {
     switch (cfg) {
+        case 5: hipLaunchKernelGGL(conv_gemm_tn3, g, dim3(256), 0, stream, p); break;
         case 4: hipLaunchKernelGGL((conv_gemm_tn<128, 128, 16>), g, dim3(256), 0, stream, p); break;
         case 3: hipLaunchKernelGGL((conv_gemm_tn<64, 64, 32>), g, dim3(256), 0, stream, p); break;
         case 2: hipLaunchKernelGGL((conv_gemm_tn2<128, 128, 16, 3>), g, dim3(256), 0, stream, p); break;
@@ -1549,9 +1927,28 @@ extern "C" int taco_wgrad_group(const TacoWgrad* items, int count, hipStream_t s
     // a group shares the chip: the per-problem split targets fewer workgroups than a lone launch would
     static const int grp_wgs = env_int("TACO_TN_GROUP_WGS", 1024);
     struct Planned { ConvGemm p; dim3 g; double work; };
-    Planned pl[TACO_WG_MAX];
-    int n = 0;
+    Planned pl[TACO_WG_MAX], pl3[TACO_WG_MAX];
+    int n = 0, n3 = 0;
+    auto flush3 = [&]() {                                   // the bf16x3 problems of the run: one grouped launch of their own
+        if (!n3) return;
+        for (int a = 1; a < n3; ++a) {
+            Planned t = pl3[a]; int b = a - 1;
+            while (b >= 0 && pl3[b].work < t.work) { pl3[b + 1] = pl3[b]; --b; }
+            pl3[b + 1] = t;
+        }
+        WgradGroup grp;
+        grp.count = n3;
+        int first = 0;
+        for (int a = 0; a < n3; ++a) {
+            grp.first[a] = first; grp.gx[a] = (unsigned short)pl3[a].g.x; grp.gy[a] = (unsigned short)pl3[a].g.y; grp.p[a] = pl3[a].p;
+            first += (int)(pl3[a].g.x * pl3[a].g.y * pl3[a].g.z);
+        }
+        for (int a = n3; a <= TACO_WG_MAX; ++a) grp.first[a] = first;
+        hipLaunchKernelGGL(conv_gemm_tn3_group, dim3(first), dim3(256), 0, stream, grp);
+        n3 = 0;
+    };
     auto flush = [&]() {
+        flush3();
         if (!n) return;
         for (int a = 1; a < n; ++a) {                     // insertion sort, descending work
             Planned t = pl[a]; int b = a - 1;
@@ -1576,6 +1973,12 @@ extern "C" int taco_wgrad_group(const TacoWgrad* items, int count, hipStream_t s
                                     it.ldw, it.shift, grp_wgs, it.dbias)) return e;
         if (it.dbias && !p.dbias)            // a problem whose bias gradient cannot ride on its GEMM: column sums in a launch of their own
             if (int e = taco_col_sum(it.dY, it.lddy, it.dbias, it.M, it.Cout, stream)) return e;
+        if (cfg == 5 && g.x <= 65535 && g.y <= 65535) {
+            pl3[n3].p = p; pl3[n3].g = g;
+            pl3[n3].work = (double)g.x * g.y * g.z * cdiv(cdiv(it.M, 32), p.splitk);
+            if (++n3 == TACO_WG_MAX) flush3();
+            continue;
+        }
         if (cfg > 1 || g.x > 65535 || g.y > 65535) { launch_bwd_weight(p, g, cfg, stream); continue; }
         pl[n].p = p; pl[n].g = g;
         pl[n].work = (double)g.x * g.y * g.z * cdiv(cdiv(it.M, 32), p.splitk);
