@@ -17,6 +17,7 @@ Prints ONE JSON line (rank 0).  Besides the contract fields:
   kernel_families      the same figures for every timed family (the recurrences are latency-bound: their fraction of the
                        MFMA peak is reported as what it is)
   gemm_roofline        the largest single MFMA launch (post-net proj_1 conv) timed back to back in isolation
+  gemm_products        which GEMMs multiply as three bf16 MFMAs per fp32 product (TACO_X3) and the step time with exact fp32 products
   step_roofline        the whole step: 349.5 GFLOP / ms_per_step vs the same peak, and 1.56 GB vs 8 TB/s
   parity               max relative error / mean |diff| of mel and linear outputs vs the fp32 CPU restatement on the bench batch
   cpu_baseline         the CPU stand-in (oracle/tacotron_torch.py, fp32, same step) on this box's host cores (rank 0, N=1 only);
@@ -525,6 +526,33 @@ def main():
             out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
         else:
             out['cpu_baseline'] = None
+        if world == 1:
+            # the large GEMMs of the backward pass multiply on the BF16 matrix pipe, three MFMAs per fp32 product (TACO_X3, gemm.hip);
+            # the same eager steps with exact fp32 products everywhere, and with the forward GEMMs on the BF16 pipe as well
+            def mode_leg(mode):
+                prev = os.environ.get('TACO_X3')
+                os.environ['TACO_X3'] = mode
+                try:
+                    for i in range(5):
+                        eager_step(i)
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    for i in range(a.steps):
+                        eager_step(i)
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / a.steps * 1e3
+                finally:
+                    if prev is None:
+                        os.environ.pop('TACO_X3', None)
+                    else:
+                        os.environ['TACO_X3'] = prev
+            out['gemm_products'] = {
+                'mode': os.environ.get('TACO_X3', '1'),
+                'note': 'TACO_X3: 0 = exact fp32 products (v_mfma_f32_32x32x2_f32) everywhere; 1 (default, the timed steps) = input- and '
+                        'weight-gradient GEMMs of the large layers as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 '
+                        'accumulation (error ~4e-6 of the result norm against float64; forward pass and every recurrence exact fp32); '
+                        '2 = the forward GEMMs too',
+                'ms_per_step_exact_fp32_products': mode_leg('0'),
+                'ms_per_step_forward_too': mode_leg('2')}
         if world == 1 and not a.no_train_loop:
             out.update(train_loop_legs(model, eng, cfg, a.steps, a.warmup))
             out['dp_machinery'] = dp_machinery_leg(eng, pool, a.steps)

@@ -1649,7 +1649,7 @@ static int launch_nn(ConvGemm p, hipStream_t stream) {
     }
     // bf16x3 products (conv_gemm_nn3) for the large problems, only on request (TACO_X3=2): the forward pass takes the ReLU / max-pool
     // decisions, and products good to 2^-17 flip ~6x more near-ties against the float64 oracle than fp32 products do
-    static const int x3_min_tiles = env_int("TACO_X3_MIN_TILES", 256);
+    static const int x3_min_tiles = env_int("TACO_X3_MIN_TILES", 128);
     if (x3_mode() >= 2 && force_cfg < 0 && tiles128 * p.splitk >= x3_min_tiles && p.N >= 64 && (!p.bank || p.cpb == 128)) {
         dim3 g3(cdiv(p.M, 128), cdiv(p.N, 128), p.splitk);
         if (p.K % 32) hipLaunchKernelGGL((conv_gemm_nn3<true>), g3, dim3(256), 0, stream, p);
@@ -1767,7 +1767,7 @@ static void launch_nt(const ConvGemm& p, hipStream_t stream) {
         return;
     }
     // bf16x3 products (conv_gemm_nt3) for the large problems: >= 256 tiles of 128 x 128.  TACO_X3=0: exact fp32 products everywhere
-    static const int x3_min_tiles = env_int("TACO_X3_MIN_TILES", 256);
+    static const int x3_min_tiles = env_int("TACO_X3_MIN_TILES", 128);
     if (x3_mode() >= 1 && force_cfg < 0 && (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk >= x3_min_tiles && p.N >= 64) {
         dim3 g3(cdiv(p.M, 128), cdiv(p.N, 128), p.splitk);
         if (p.K % 32) hipLaunchKernelGGL((conv_gemm_nt3<true>), g3, dim3(256), 0, stream, p);

@@ -417,6 +417,56 @@ def test_conv_gemm_forward_backward(M, T, cin, cout, kw):
     assert float(dw[:, :, cout:].abs().max()) == 0 if ldw > cout else True
 
 
+@pytest.mark.parametrize('M,T,cin,cout,kw,bank', [(13101, 397, 132, 260, 3, 0),      # ragged M / N, K tails (260 % 32, 132 % 32), sequence ends under taps
+                                                  (10240, 10240, 256, 1025, 1, 0),     # the linear layer: 1025 columns in rows of 1028
+                                                  (20480, 640, 80, 1024, 8, 8),        # post-net bank: 80 channels (flat weight-gradient rows)
+                                                  (4096, 128, 128, 2048, 16, 16),      # encoder bank: split over the taps (input gradient)
+                                                  (8320, 208, 1024, 256, 3, 0)])
+def test_bf16x3_gemms_against_float64(M, T, cin, cout, kw, bank, monkeypatch):
+    """The three-MFMA bf16 product kernels (conv_gemm_nn3 / nt3 / tn3; TACO_X3, csrc/gemm.hip) on shapes that reach their tile thresholds:
+    forward (mode 2 only), input gradient and weight gradient (default mode 1) against float64.  Tolerance 2e-5 of the result's largest
+    element (measured 3-5e-6; exact fp32 products: 5e-7 -- the x3 results must DIFFER from those, which shows the x3 kernels ran)."""
+    from tacotron_multispeaker_amd._lib import lib, stream
+    dev = 'cuda'
+    torch.manual_seed(M + kw)
+    ldw = 128 if bank else (cout + 3) & ~3
+    taps = kw * (kw + 1) // 2 if bank else kw
+    co = 128 if bank else cout
+    x = torch.randn(M, cin, device=dev)
+    w = torch.zeros(taps, cin, ldw, device=dev); w[:, :, :co] = torch.randn(taps, cin, co, device=dev) / np.sqrt(cin * kw)
+    b = torch.randn(max(ldw, cout), device=dev)
+    lddy = cout if bank else (cout + 3) & ~3
+    dy = torch.zeros(M, lddy, device=dev); dy[:, :cout] = torch.randn(M, cout, device=dev)
+    x64 = x.double().requires_grad_(True)
+    widths = list(range(1, kw + 1)) if bank else [kw]
+    w64, k0 = [], 0
+    for k in widths:
+        w64.append(w[k0:k0 + k, :, :co].double().requires_grad_(True)); k0 += k
+    pre = torch.cat([_conv_ref(x64, wk, b[i * co:(i + 1) * co].double(), T) for i, wk in enumerate(w64)], 1)
+    pre.backward(dy[:, :cout].double())
+    ref_y = torch.relu(pre).detach().cpu().numpy()
+    ref_dx = x64.grad.cpu().numpy()
+    ref_dw = torch.cat([wk.grad for wk in w64], 0).cpu().numpy()
+
+    def run(mode):
+        monkeypatch.setenv('TACO_X3', mode)
+        y = torch.empty(M, cout, device=dev); dx = torch.empty(M, cin, device=dev); dw = torch.zeros_like(w)
+        lib.taco_conv_gemm_fwd(x, w, b, y, M, T, cin, cout, kw, bank, cin, ldw, cout, 1, 0, stream())
+        lib.taco_conv_gemm_bwd_data(dy, w, dx, M, T, cin, cout if bank else lddy, kw, bank, lddy, ldw, cin, 0, stream())
+        lib.taco_conv_gemm_bwd_weight(x, dy, dw, M, T, cin, cout, kw, bank, cin, lddy, ldw, stream())
+        torch.cuda.synchronize()
+        return y.cpu().numpy(), dx.cpu().numpy(), dw[:, :, :co].cpu().numpy(), dw
+    y0, dx0, dw0, _ = run('0')
+    y1, dx1, dw1, dwfull = run('1')
+    y2, dx2, dw2, _ = run('2')
+    assert rel(y0, ref_y) < 2e-6 and rel(dx0, ref_dx) < 3e-6 and rel(dw0, ref_dw) < 3e-6
+    assert np.array_equal(y1, y0)                                        # mode 1 leaves the forward pass alone
+    for got, ref in ((dx1, ref_dx), (dw1, ref_dw), (y2, ref_y), (dx2, ref_dx), (dw2, ref_dw)):
+        assert rel(got, ref) < 2e-5
+    assert not np.array_equal(dx1, dx0) and not np.array_equal(dw1, dw0) and not np.array_equal(y2, y0)
+    assert float(dwfull[:, :, co:].abs().max()) == 0 if ldw > co else True
+
+
 @pytest.mark.parametrize('N,T,cin,K', [(3, 20, 128, 16), (2, 35, 80, 8), (32, 128, 128, 16),
                                        # weight gradient over the flattened (tap, channel) rows (Cin not a multiple of the 64-row tile: a tile
                                        # holds channels of two or more taps, each with its own row shift): post-net shape, sequences shorter
