@@ -8,7 +8,7 @@ root = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join('profiles', 'r03_pmc_traffic.json')
 FAMILIES = collections.OrderedDict([
-    ('dW GEMM (conv_gemm_tn2_group)', 'conv_gemm_tn2_group'), ('dX GEMM (conv_gemm_nt2)', 'conv_gemm_nt2'),
+    ('dW GEMM (conv_gemm_tn2_group)', ('conv_gemm_tn3_group', 'conv_gemm_tn2_group')), ('dX GEMM (conv_gemm_nt2)', ('conv_gemm_nt2', 'conv_gemm_nt3')),
     ('fwd GEMM (conv_gemm_nn2)', 'conv_gemm_nn2'), ('attention recurrence bwd (attn_cluster_bwd_k)', 'attn_cluster_bwd_k'),
     ('attention recurrence fwd (attn_cluster_fwd_k)', 'attn_cluster_fwd_k'),
     ('decoder GRU(256) bwd (gru256_cluster_bwd_k)', 'gru256_cluster_bwd_k'), ('decoder GRU(256) fwd (gru256_cluster_fwd_k)', 'gru256_cluster_fwd_k'),
@@ -25,7 +25,7 @@ def sums(counter):
             if r['Counter_Name'] != counter:
                 continue
             for fam, key in FAMILIES.items():
-                if key in r['Kernel_Name']:
+                if any(k in r['Kernel_Name'] for k in ((key,) if isinstance(key, str) else key)):
                     tot[fam] += float(r['Counter_Value']); n[fam] += 1
     return tot, n
 
@@ -38,7 +38,7 @@ for fam in FAMILIES:
         continue
     fb, wb = fetch[fam] * 1024.0 * 2.0 / nf[fam], write[fam] * 1024.0 / nw[fam]
     res[fam] = {'bytes_per_launch': fb + wb, 'fetch_bytes_per_launch_corrected_x2': fb, 'write_bytes_per_launch': wb,
-                'launches_per_step': nf[fam] / steps, 'source': SRC}
+                'launches_per_step': nf[fam] / steps, 'bytes_per_step': (fb + wb) * nf[fam] / steps, 'source': SRC}
 json.dump(res, open(out, 'w'), indent=1)
 for k, v in res.items():
     print('%-50s %8.1f MB/launch (fetch %.1f, write %.1f) x %.1f launches/step' % (k, v['bytes_per_launch'] / 1e6,
