@@ -681,6 +681,11 @@ class Engine:
         first = [True]
 
         def launch(s0, s1, pad):
+            if sc == 'encoder_cbhg' and not pad:
+                # the encoder's BPTT runs beside the decoder's weight-gradient GEMMs: with its CUs to itself (150 KB of unused LDS, like the
+                # decoder GRUs) it takes ~100 us instead of ~250 on the main stream's chain; C2 6.62 -> 6.56 ms (100 KB: a GEMM workgroup
+                # still fits beside it, no gain).  Not with more than one rank: the exchange's kernels need CUs too (_gru256_pad).
+                pad = int(os.environ.get('TACO_ENC_GRU_PAD', '150000' if self.world == 1 else '0'))
             self._timed('biGRU(128) bwd (gru128_seq_bwd_k)', 2.0 * 2 * N * (s1 - s0) * 128 * 384,
                         lambda: lib.taco_gru128_seq_bwd(dOUT, 256, self.P(sc + '/bigru/fw_whg'), self.P(sc + '/bigru/fw_whc'),
                                                         self.P(sc + '/bigru/bw_whg'), self.P(sc + '/bigru/bw_whc'), lengths, OUT, 256, RUC,
