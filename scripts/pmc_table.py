@@ -4,7 +4,9 @@ import csv, sys
 rows = {r['kernel']: r for r in csv.DictReader(open(sys.argv[1]))}
 want = ['attn_cluster_fwd_k<true, 2>', 'attn_cluster_bwd_k<true, 2>', 'gru256_cluster_fwd_k', 'gru256_cluster_bwd_k', 'gru128_seq_fwd_k<512>',
         'gru128_seq_bwd_k<512>', 'highway4_fwd_k', 'highway4_bwd_k', 'conv_gemm_tn2_group<64, 64, 32, 3>', 'conv_gemm_nt2<64, 64, 32, 3, false>',
-        'conv_gemm_nn2<64, 64, 32, 3, false>']
+        'conv_gemm_nn2<64, 64, 32, 3, false>', 'conv_gemm_tn3_group', 'conv_gemm_nt3<false>']
+if len(sys.argv) > 2:                  # restrict to kernels whose name contains one of the given substrings
+    want = [k for k in rows if any(a in k for a in sys.argv[2:])]
 ks = [k for k in want if k in rows]
 ctrs = ['SQ_WAVE_CYCLES', 'SQ_BUSY_CU_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS',
         'SQ_ACTIVE_INST_SCA', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU', 'SQ_INSTS_VMEM_RD',

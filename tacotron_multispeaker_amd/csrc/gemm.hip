@@ -985,20 +985,26 @@ __global__ __launch_bounds__(256) void conv_gemm_nn3(ConvGemm p) {
     bool need_tap = true;
     u32x4_t ra[NV];
     float rb[NV][4];
+    unsigned vob[NV][4], vob_last[NV][4];        // loop-invariant lane offsets of the 16 weight loads (the k walk is the scalar soffset)
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kl = (bq + 2 * v) * 4 + i;
+            vob[v][i] = vob_col == TACO_OOB ? TACO_OOB : vob_col + (unsigned)(kl * ldb) * 4u;
+            vob_last[v][i] = klast + kl < p.K ? vob[v][i] : TACO_OOB;
+        }
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, 0x7FFFFFFF, 0x00020000);
     auto load = [&]() {
         if (need_tap) { tap_offsets(i_j); need_tap = false; }
         const bool last = KTAIL && i_kc == ksteps - 1;
 #pragma unroll
         for (int v = 0; v < NV; ++v) ra[v] = buf_load16(p.A, last ? voa_last[v] : voa[v], soa);
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kl = (bq + 2 * v) * 4 + i;
-                const bool ok = !KTAIL || !last || klast + kl < p.K;
-                rb[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? vob_col + (unsigned)(kl * ldb) * 4u : TACO_OOB, sob, 0));
-            }
+            for (int i = 0; i < 4; ++i)
+                rb[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, last ? vob_last[v][i] : vob[v][i], sob, 0));
         ++i_kc; ++issued; soa += BK * 4; sob += bstep;
         if (i_kc == ksteps) { i_kc = 0; ++i_j; soa = 0; sob = __builtin_amdgcn_readfirstlane(i_j * btap); need_tap = true; }
     };
@@ -1404,28 +1410,44 @@ __device__ __forceinline__ void tn3_body(const ConvGemm& p, const int bx, const 
     int t0 = (kt0 * BK) % p.T;
     const int astep = BK * p.lda * 4, bstep = BK * p.ldb * 4;
     int soa = __builtin_amdgcn_readfirstlane(kt0 * astep), sob = __builtin_amdgcn_readfirstlane(kt0 * bstep);
+    // the 2 x 16 lane offsets of a row tile are loop-invariant (the row walk is the scalar soffset): kept in registers, so that an interior
+    // tile issues its 32 loads with no address arithmetic (rocprofv3 counted 9 non-MFMA vector and 10 scalar instructions per MFMA in the
+    // first version of this kernel, a third of them these offsets and their selects)
+    unsigned oa0[4][4], ob0[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = (q0 + 2 * v) * 4 + i;
+            oa0[v][i] = voa == TACO_OOB ? TACO_OOB : voa + (unsigned)(ml * p.lda) * 4u;
+            ob0[v][i] = vob == TACO_OOB ? TACO_OOB : vob + (unsigned)(ml * p.ldb) * 4u;
+        }
+    const auto ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bbase), 0, 0x7FFFFFFF, 0x00020000);
     float ra[4][4], rb[4][4];
     auto load = [&]() {
         const int mbase = i_kt * BK;
         const bool full = mbase + BK <= p.M;
         const bool interior = full && ((shift == 0 && shift_hi == 0) || (t0 + shift >= 0 && t0 + BK - 1 + shift_hi < p.T && t0 + BK - 1 < p.T));
-        const auto ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, 0x7FFFFFFF, 0x00020000);
-        const auto rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bbase), 0, 0x7FFFFFFF, 0x00020000);
+        if (interior) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+            for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ml = (q0 + 2 * v) * 4 + i;
-                unsigned oa = voa == TACO_OOB ? TACO_OOB : voa + (unsigned)(ml * p.lda) * 4u;
-                unsigned ob = vob == TACO_OOB ? TACO_OOB : vob + (unsigned)(ml * p.ldb) * 4u;
-                if (!interior) {
-                    const int m = mbase + ml;
-                    if (!(m < p.M && (unsigned)(m % p.T + shift + jl) < (unsigned)p.T)) oa = TACO_OOB;
-                    if (!(m < p.M)) ob = TACO_OOB;
+                for (int i = 0; i < 4; ++i) {
+                    ra[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra_rsrc, oa0[v][i], soa, 0));
+                    rb[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, ob0[v][i], sob, 0));
                 }
-                ra[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra_rsrc, oa, soa, 0));
-                rb[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, ob, sob, 0));
-            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mbase + (q0 + 2 * v) * 4 + i;
+                    const bool oka = m < p.M && (unsigned)(m % p.T + shift + jl) < (unsigned)p.T, okb = m < p.M;
+                    ra[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra_rsrc, oka ? oa0[v][i] : TACO_OOB, soa, 0));
+                    rb[v][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, okb ? ob0[v][i] : TACO_OOB, sob, 0));
+                }
+        }
         ++i_kt; ++issued; soa += astep; sob += bstep;
         t0 += BK; if (t0 >= p.T) t0 %= p.T;
     };
