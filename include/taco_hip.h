@@ -29,7 +29,11 @@ typedef struct ihipStream_t* hipStream_t;
  * (models/modules.py:95-100) incl. the K-wide conv bank (models/modules.py:39-42).
  * X [M=N*T, Cin]; W TF layout [kw, Cin, Cout] (ldw = row stride of the [Cin, Cout] slices); Y [M, Cout].
  * bank_K > 0: fused bank of widths 1..bank_K, 128 channels each, W packed [sum k][Cin][128], Y [M, bank_K*128].
- * act: 0 none, 1 relu, 2 sigmoid, 3 tanh.  Dense layer: kw = 1, T = M. */
+ * act: 0 none, 1 relu, 2 sigmoid, 3 tanh.  Dense layer: kw = 1, T = M.
+ * Arithmetic: fp32 in, fp32 accumulate.  Products are exact fp32 (v_mfma_f32_32x32x2_f32) except, by default, in the input- and
+ * weight-gradient entry points on LARGE problems (>= 128 output tiles of 128 x 128, >= 2 GFLOP for weight gradients), where a product is
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi of bf16 parts on v_mfma_f32_32x32x16_bf16 (error ~4e-6 of the result norm).  Environment TACO_X3, read at
+ * every launch: 0 = exact fp32 products everywhere, 1 = as described (default), 2 = the forward entry points too. */
 int taco_conv_gemm_fwd(const float* X, const float* W, const float* bias, float* Y, int M, int T, int Cin, int Cout,
                        int kw, int bank_K, int ldx, int ldw, int ldy, int act, int accumulate, hipStream_t stream);
 /* the same over the FRAMES [t0, t1) of every length-T sequence of X / Y [N*T, .] (taps read the full sequences: the rows a tap
